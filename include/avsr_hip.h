@@ -1,0 +1,214 @@
+/*
+ * avsr_hip.h - C ABI of libavsr_hip.so: hand-written HIP (gfx950 / CDNA4)
+ * kernels for the audio-visual forward/backward of the reference's
+ * models/av_net.py.
+ *
+ * The reference has no FFI, plugin table or native code: every entry below
+ * replaces a *library call* the reference's Python makes (PyTorch / cuDNN /
+ * cuBLAS through nn.Module calls).  The reference call site each entry stands
+ * in for is cited as file:line relative to the reference checkout;
+ * "hf:" = transformers/models/whisper/modeling_whisper.py.
+ *
+ * Conventions
+ *  - raw device pointers, explicit sizes / leading dimensions (in ELEMENTS),
+ *    a hipStream_t; the caller allocates every output and workspace;
+ *  - returns 0 on success, a negative AVSR_E* code on a bad argument or an
+ *    unsupported shape, never throws, never aborts; HIP launch errors are
+ *    returned as AVSR_EHIP;
+ *  - stream ordered, no implicit synchronisation, no hidden global state,
+ *    no allocation;
+ *  - dtype codes: AVSR_F32 = 0, AVSR_BF16 = 1.  "act" is the activation
+ *    storage type; accumulation is always fp32.
+ */
+#ifndef AVSR_HIP_H
+#define AVSR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* avsr_stream_t; /* hipStream_t */
+
+enum { AVSR_F32 = 0, AVSR_BF16 = 1 };
+/* RELU_AFTER_RESIDUAL: relu(residual + v), the tail of a ResNet bottleneck */
+enum { AVSR_ACT_NONE = 0, AVSR_ACT_GELU = 1, AVSR_ACT_RELU = 2, AVSR_ACT_RELU_AFTER_RESIDUAL = 3 };
+enum { AVSR_OK = 0, AVSR_EINVAL = -1, AVSR_EUNSUPPORTED = -2, AVSR_EHIP = -3 };
+
+/* library / build identification: returns a static string */
+const char* avsr_version(void);
+
+/* ------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C[m,n] = epi( sum_k A[m,k] * B[n,k] )   ("NT")
+ * Replaces every nn.Linear / F.linear on the path (models/av_net.py:35,48,
+ * models/gate_cross_attention.py:16,23-25,56-57, models/utils.py:34,
+ * hf:277-281,374-376) and, in conv mode, the im2col GEMM of nn.Conv1d /
+ * nn.Conv2d (hf:566-567, torchvision Bottleneck convs instantiated at
+ * models/moco_visual_frontend.py:20).
+ *
+ * epilogue, in this order:  v = acc * alpha;  v *= scale[n];  v += bias[n];
+ *   v = act(v);  v = residual[m,n] + g * v  (g = tanh(*gate) or 1);
+ *   (AVSR_ACT_RELU_AFTER_RESIDUAL applies the ReLU after the residual add;)
+ *   optional per-column sums of the PRE-activation value into col_sum /
+ *   col_sumsq (fp32 atomics) for batch-norm statistics.
+ *
+ * conv mode (conv.enabled): A is an NHWC image [n_img,H,W,C]; row m of the
+ * implicit A matrix is output pixel (img,oh,ow), column k = (kh*KW+kw)*C + c;
+ * B is [N][KH*KW*C]; C is the NHWC output [n_img*OH*OW, N].  M must equal
+ * n_img*OH*OW and K must equal KH*KW*C.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int32_t in_dtype;   /* dtype of A and B */
+    int32_t out_dtype;  /* dtype of C and residual */
+    int64_t M, N, K;
+    const void* A; int64_t lda;
+    const void* B; int64_t ldb;
+    void* C; int64_t ldc;
+    int64_t batch;      /* >= 1 */
+    int64_t strideA, strideB, strideC; /* elements between batch items */
+    float alpha;
+    const float* scale;   /* [N] or NULL */
+    const float* bias;    /* [N] or NULL */
+    int32_t act;
+    const void* residual; /* [M,N] (ld = ldr) of out_dtype, or NULL */
+    int64_t ldr;
+    int64_t res_period;   /* > 0: residual row = m % res_period (a [period,N] table, e.g. positions) */
+    const float* gate;    /* device scalar or NULL */
+    float* col_sum;       /* [N] or NULL */
+    float* col_sumsq;     /* [N] or NULL */
+    struct {
+        int32_t enabled;
+        int32_t H, W, C, KH, KW, stride, pad, OH, OW;
+    } conv;
+} avsr_gemm_t;
+
+int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g);
+
+/* ------------------------------------------------------------------------
+ * LayerNorm over the last dimension, one wave per row, fp32 statistics.
+ * Replaces nn.LayerNorm / the fp32-upcasting LayerNorm subclass
+ * (models/gate_cross_attention.py:8-10; hf:371,377,573).  `add` (optional)
+ * is a [add_period, D] fp32 table added after the affine, row r uses
+ * add[r % add_period] - the sinusoidal PositionalEncoding of
+ * models/utils.py:21-28 fused behind audio_ln / video_ln
+ * (models/av_net.py:83-84,88-89).  mean / rstd (optional) are saved for the
+ * backward.  D % 4 == 0, D <= 2048.
+ * ---------------------------------------------------------------------- */
+int avsr_layernorm_fwd(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, int64_t ldx,
+                       void* y, int64_t ldy, const float* gamma, const float* beta, const float* add,
+                       int64_t add_period, float* mean, float* rstd, int64_t rows, int64_t D, float eps);
+/* dgamma / dbeta are ACCUMULATED into (fp32 atomics); zero them first. */
+int avsr_layernorm_bwd(avsr_stream_t stream, int x_dtype, int g_dtype, const void* dy, int64_t lddy,
+                       const void* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
+                       void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int64_t D);
+
+/* ------------------------------------------------------------------------
+ * Attention, head_dim 64.  Element (b,t,h,d) of Q/K/V/O lives at
+ * ptr + (b*T + t)*ld + h*64 + d.  key_mask: uint8 [B,Tk], 1 = ignore key
+ * (key_padding_mask of nn.MultiheadAttention, models/gate_cross_attention.py:40);
+ * a query row whose keys are all masked yields zeros.  lse (optional for the
+ * forward, required by the backward): fp32 [B,H,Tq].
+ * use_mfma = 1: bf16 flash kernel on v_mfma_f32_32x32x16_bf16, no dropout
+ *   (the Whisper encoder self-attention, hf:284-356 / 215-238).
+ * use_mfma = 0: exact fp32-math kernel, any dtype, attention dropout with the
+ *   counter-based generator keyed by (seed, ((b*H+h)*Tq+q)*Tk+k).
+ * ---------------------------------------------------------------------- */
+int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
+                  int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
+                  float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
+                  float p_drop, uint64_t seed);
+/* d_ws: fp32 [B,H,Tq] scratch (row sums of dO*O). */
+int avsr_attn_bwd(avsr_stream_t stream, int dtype, const void* Q, int64_t ldq, const void* K, int64_t ldk,
+                  const void* V, int64_t ldv, const void* O, int64_t ldo, const void* dO, int64_t lddo,
+                  void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv,
+                  const uint8_t* key_mask, const float* lse, float* d_ws, int64_t B, int64_t H, int64_t Tq,
+                  int64_t Tk, int64_t head_dim, float scale, float p_drop, uint64_t seed);
+
+/* ------------------------------------------------------------------------
+ * Visual frontend pieces (models/moco_visual_frontend.py).
+ * avsr_stem3d_fwd: Conv3d(3,64,(5,3,3),s(1,2,2),p(2,3,3),bias=False) (:15) on
+ *   video [B,T,3,H,W] fp32 -> NHWC [B*T,OH,OW,64].  With scale/shift the
+ *   eval-mode BatchNorm3d + ReLU (:16-17) are folded in; otherwise the raw
+ *   convolution is stored and per-channel sum / sum-of-squares accumulate
+ *   into col_sum / col_sumsq (training-mode batch statistics).
+ * avsr_maxpool3x3s2: MaxPool3d((1,3,3),(1,2,2),(0,1,1)) (:18) over NHWC, with
+ *   an optional per-channel affine + ReLU applied to each element first.
+ * avsr_avgpool_mask_fwd: AdaptiveAvgPool2d(1) of the trunk + masked_fill of
+ *   frames t >= lens[b] (:42,45,49).
+ * avsr_bn_*: BatchNorm2d/3d in training mode (batch statistics -> affine,
+ *   running-stat update with the unbiased variance) and eval mode (fold).
+ * ---------------------------------------------------------------------- */
+int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float* video, const float* weight, void* out,
+                    const float* scale, const float* shift, float* col_sum, float* col_sumsq, int64_t B,
+                    int64_t T, int64_t H, int64_t W);
+int avsr_maxpool3x3s2(avsr_stream_t stream, int dtype, const void* x, void* y, const float* scale,
+                      const float* shift, int64_t N, int64_t H, int64_t W, int64_t C);
+int avsr_avgpool_mask_fwd(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y,
+                          const int64_t* lens, int64_t B, int64_t T, int64_t HW, int64_t C);
+int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq, double count,
+                     const float* weight, const float* bias, float* running_mean, float* running_var,
+                     float* scale, float* shift, int64_t C, float eps, float momentum);
+int avsr_bn_fold(avsr_stream_t stream, const float* weight, const float* bias, const float* running_mean,
+                 const float* running_var, float* scale, float* shift, int64_t C, float eps);
+int avsr_bn_apply(avsr_stream_t stream, int dtype, const void* x, const void* residual, void* y,
+                  const float* scale, const float* shift, int64_t rows, int64_t C, int relu);
+
+/* ------------------------------------------------------------------------
+ * Head losses on fp32 logits [B*T, V] (train.py:95-128,137): row
+ * log-sum-exp, CTC(blank, mean, zero_infinity) on log_softmax(logits) and
+ * label-smoothed cross entropy over the first min(T, target_width) frames.
+ * targets: int64 [B, ldt]; target_width = targets.shape[1].
+ * out3 = {ctc, ce, number of CE targets kept}.  The workspace (size from
+ * avsr_head_loss_workspace_floats) carries lse / alpha / beta to the backward,
+ * which writes d(w_ctc*ctc + w_ce*ce)/d(logits) * upstream[0].
+ * ---------------------------------------------------------------------- */
+int64_t avsr_head_loss_workspace_floats(int64_t B, int64_t T, int64_t target_width);
+int avsr_head_loss_fwd(avsr_stream_t stream, const float* logits, int64_t ld, int64_t B, int64_t T, int64_t V,
+                       const int64_t* targets, int64_t ldt, int64_t target_width, const int64_t* input_lengths,
+                       const int64_t* target_lengths, float label_smoothing, int64_t ignore_index,
+                       int64_t blank, float* ws, float* out3);
+int avsr_head_loss_bwd(avsr_stream_t stream, int grad_dtype, const float* logits, int64_t ld, int64_t B,
+                       int64_t T, int64_t V, const int64_t* targets, int64_t ldt, int64_t target_width,
+                       const int64_t* input_lengths, const int64_t* target_lengths, float label_smoothing,
+                       int64_t ignore_index, int64_t blank, const float* ws, float w_ctc, float w_ce,
+                       const float* upstream, void* dlogits, int64_t lddx);
+/* torch.argmax(logits, -1) (train.py:137): first maximum wins. */
+int avsr_argmax_rows(avsr_stream_t stream, const float* x, int64_t ld, int64_t rows, int64_t V, int64_t* out);
+
+/* ------------------------------------------------------------------------
+ * Element-wise helpers around the GEMMs.
+ * ---------------------------------------------------------------------- */
+int avsr_cast(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y, int64_t n, float scale);
+/* y[b][c][r] = x[b][r][c] * scale */
+int avsr_transpose(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, int64_t ldx, int64_t sx,
+                   void* y, int64_t ldy, int64_t sy, int64_t batch, int64_t R, int64_t C, float scale);
+/* out[n] (+)= sum_m x[m][n]  (bias gradients) */
+int avsr_colsum(avsr_stream_t stream, int dtype, const void* x, int64_t ld, int64_t M, int64_t N, float* out,
+                int accumulate);
+/* exact (erf) GELU, models/gate_cross_attention.py:24 */
+int avsr_gelu_fwd(avsr_stream_t stream, int dtype, const void* x, void* y, int64_t n);
+int avsr_gelu_bwd(avsr_stream_t stream, int dtype, const void* x, const void* dy, void* dx, int64_t n);
+/* out = x + tanh(*gate) * dropout(y)  (models/gate_cross_attention.py:26,43,47);
+ * keep decision of element i = generator(seed, i).  Backward: dy =
+ * tanh(*gate)*dropout(dout), *dgate += (1-tanh^2) * sum(dout*dropout(y)). */
+int avsr_gated_residual_fwd(avsr_stream_t stream, int dtype, const void* x, const void* y, const float* gate,
+                            void* out, int64_t n, float p_drop, uint64_t seed);
+int avsr_gated_residual_bwd(avsr_stream_t stream, int dtype, const void* dout, const void* y, const float* gate,
+                            void* dy, float* dgate, int64_t n, float p_drop, uint64_t seed);
+/* out = a + b + c (c may be NULL)  (models/av_net.py:106) */
+int avsr_add3(avsr_stream_t stream, int dtype, const void* a, const void* b, const void* c, void* out, int64_t n);
+
+/* ------------------------------------------------------------------------
+ * Optimizer step of train.py:218-225,321: global-norm clipping and AdamW over
+ * flat fp32 buffers.  *out += sum(x^2);  *scale = min(1, max_norm/(norm+1e-6)).
+ * ---------------------------------------------------------------------- */
+int avsr_sumsq_accumulate(avsr_stream_t stream, const float* x, int64_t n, float* out);
+int avsr_clip_scale(avsr_stream_t stream, const float* sumsq, float max_norm, float* scale, float* norm_out);
+int avsr_adamw_step(avsr_stream_t stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                    void* bf16_shadow, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, const float* grad_scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVSR_HIP_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of libavsr_hip.so - the C ABI declared in include/avsr_hip.h.
+
+The library is built in-tree (``make -C mocov2_whisper_flamingo_amd/csrc``).  There
+is no fallback: if it cannot be loaded, every op raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavsr_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_RELU_AFTER_RESIDUAL = 0, 1, 2, 3
+
+_c = ctypes
+_vp, _i64, _i32, _f32, _u64, _f64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_float, _c.c_uint64, _c.c_double
+
+
+class ConvDesc(_c.Structure):
+    _fields_ = [(n, _i32) for n in ("enabled", "H", "W", "C", "KH", "KW", "stride", "pad", "OH", "OW")]
+
+
+class GemmDesc(_c.Structure):
+    _fields_ = [
+        ("in_dtype", _i32), ("out_dtype", _i32),
+        ("M", _i64), ("N", _i64), ("K", _i64),
+        ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
+        ("batch", _i64), ("strideA", _i64), ("strideB", _i64), ("strideC", _i64),
+        ("alpha", _f32), ("scale", _vp), ("bias", _vp), ("act", _i32),
+        ("residual", _vp), ("ldr", _i64), ("res_period", _i64), ("gate", _vp),
+        ("col_sum", _vp), ("col_sumsq", _vp), ("conv", ConvDesc),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/avsr_hip.h declares
+SIGNATURES = {
+    "avsr_version": (_c.c_char_p, []),
+    "avsr_gemm_nt": (_i32, [_vp, _c.POINTER(GemmDesc)]),
+    "avsr_layernorm_fwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _f32]),
+    "avsr_layernorm_bwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64]),
+    "avsr_attn_fwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
+                             _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64]),
+    "avsr_attn_bwd": (_i32, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
+                             _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64]),
+    "avsr_stem3d_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
+    "avsr_maxpool3x3s2": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
+    "avsr_avgpool_mask_fwd": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
+    "avsr_bn_finalize": (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32]),
+    "avsr_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32]),
+    "avsr_bn_apply": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32]),
+    "avsr_head_loss_workspace_floats": (_i64, [_i64, _i64, _i64]),
+    "avsr_head_loss_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _i64, _i64, _vp, _vp]),
+    "avsr_head_loss_bwd": (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _i64, _i64,
+                                  _vp, _f32, _f32, _vp, _vp, _i64]),
+    "avsr_argmax_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp]),
+    "avsr_cast": (_i32, [_vp, _i32, _i32, _vp, _vp, _i64, _f32]),
+    "avsr_transpose": (_i32, [_vp, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _f32]),
+    "avsr_colsum": (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _vp, _i32]),
+    "avsr_gelu_fwd": (_i32, [_vp, _i32, _vp, _vp, _i64]),
+    "avsr_gelu_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64]),
+    "avsr_gated_residual_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _u64]),
+    "avsr_gated_residual_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _u64]),
+    "avsr_add3": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64]),
+    "avsr_sumsq_accumulate": (_i32, [_vp, _vp, _i64, _vp]),
+    "avsr_clip_scale": (_i32, [_vp, _vp, _f32, _vp, _vp]),
+    "avsr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _vp]),
+}
+
+_lib = None
+
+
+class AvsrHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once and attach the prototypes; raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AvsrHipError(
+            f"{LIB_PATH} not found - build it with `make -C {os.path.join(_HERE, 'csrc')}`; "
+            "this package has no CPU or PyTorch fallback")
+    lib = _c.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "invalid argument", -2: "unsupported shape / alignment", -3: "HIP launch error"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise AvsrHipError(f"{what} failed: {_ERR.get(rc, rc)}")

@@ -1,0 +1,279 @@
+// Small HBM-bound helpers around the GEMMs: dtype casts, tiled transposes,
+// column sums (bias gradients), GELU forward / backward, the tanh-gated
+// residual with dropout (forward / backward), sums, and the fused AdamW step.
+#include "common.h"
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long n, float scale) {
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[i + e] = from_f32<TO>(to_f32<TI>(x[i + e]) * scale);
+        } else {
+            for (long j = i; j < n; ++j) y[j] = from_f32<TO>(to_f32<TI>(x[j]) * scale);
+        }
+    }
+}
+
+// y[b][c][r] = x[b][r][c] * scale  (32x32 LDS tile, padded against bank conflicts)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ x, long ldx, long sx, TO* __restrict__ y, long ldy,
+                                                        long sy, int R, int C, float scale) {
+    __shared__ float tile[32][33];
+    const TI* xb = x + (long)blockIdx.z * sx;
+    TO* yb = y + (long)blockIdx.z * sy;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? to_f32<TI>(xb[(long)r * ldx + c]) * scale : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) yb[(long)c * ldy + r] = from_f32<TO>(tile[tx][i]);
+    }
+}
+
+// out[n] (+)= sum_m x[m][n]; one block per 64 columns, 4 waves split the rows.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ld, int M, int N, float* __restrict__ out,
+                                                     int accumulate) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (n < N)
+        for (int m = w; m < M; m += 4) s += to_f32<T>(x[(long)m * ld + n]);
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && n < N) {
+        const float t = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        out[n] = accumulate ? out[n] + t : t;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = from_f32<T>(gelu_erf(to_f32<T>(x[i])));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dx[i] = from_f32<T>(to_f32<T>(dy[i]) * gelu_erf_grad(to_f32<T>(x[i])));
+}
+
+// out = x + tanh(gate) * drop(y)   (models/gate_cross_attention.py:43,47 with the
+// nn.Dropout of :26 folded in; keep decision = philox(seed, element index)).
+template <typename T>
+__global__ __launch_bounds__(256) void gated_residual_fwd_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                                 const float* __restrict__ gate, T* __restrict__ out, long n,
+                                                                 float pdrop, uint64_t seed) {
+    const float g = tanhf(gate[0]);
+    const float ks = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = to_f32<T>(y[i]);
+        if (pdrop > 0.f) v = avsr_keep(seed, (uint64_t)i, pdrop) ? v * ks : 0.f;
+        out[i] = from_f32<T>(to_f32<T>(x[i]) + g * v);
+    }
+}
+// dy = tanh(g) * drop(dout);  dgate += (1 - tanh(g)^2) * sum(dout * drop(y))
+template <typename T>
+__global__ __launch_bounds__(256) void gated_residual_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ y,
+                                                                 const float* __restrict__ gate, T* __restrict__ dy,
+                                                                 float* __restrict__ dgate, long n, float pdrop, uint64_t seed) {
+    __shared__ float red[16];
+    const float g = tanhf(gate[0]);
+    const float ks = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float d = to_f32<T>(dout[i]);
+        if (pdrop > 0.f) d = avsr_keep(seed, (uint64_t)i, pdrop) ? d * ks : 0.f;
+        acc += d * to_f32<T>(y[i]);
+        dy[i] = from_f32<T>(g * d);
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(dgate, (1.f - g * g) * acc);
+}
+
+// out = a + b + c  (models/av_net.py:106)
+template <typename T>
+__global__ __launch_bounds__(256) void add3_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+                                                   T* __restrict__ out, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = from_f32<T>(to_f32<T>(a[i]) + to_f32<T>(b[i]) + (c ? to_f32<T>(c[i]) : 0.f));
+}
+
+// out[0] += sum(x^2)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float red[16];
+    const long stride = (long)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += x[i] * x[i];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+
+// AdamW over a flat fp32 parameter buffer (torch.optim.AdamW semantics:
+// decoupled weight decay, bias-corrected moments, eps added to sqrt(v_hat)).
+// grad_scale[0] multiplies the gradient first (global-norm clipping factor);
+// a bf16 shadow copy of the new weights is written when `shadow` is set.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, long n, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1, float bc2,
+                                                    const float* __restrict__ grad_scale) {
+    const float gs = grad_scale ? grad_scale[0] : 1.f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gr = g[i] * gs;
+        float w = p[i] * (1.f - lr * wd);
+        const float mi = beta1 * m[i] + (1.f - beta1) * gr;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        w -= (lr / bc1) * mi / denom;
+        p[i] = w;
+        if (shadow) shadow[i] = (bf16_t)w;
+    }
+}
+
+// scale[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))   (torch clip_grad_norm_)
+__global__ void clip_scale_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ scale,
+                                  float* __restrict__ norm_out) {
+    const float nrm = sqrtf(sumsq[0]);
+    if (norm_out) norm_out[0] = nrm;
+    scale[0] = fminf(1.f, max_norm / (nrm + 1e-6f));
+}
+
+// --------------------------------------------------------------- host ------
+static inline unsigned grid_for(long n, int per_block, long cap) {
+    long nb = (n + per_block - 1) / per_block;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    return (unsigned)nb;
+}
+
+extern "C" int avsr_cast(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y, int64_t n, float scale) {
+    if (!x || !y || n <= 0) return AVSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(grid_for(n, 1024, 8192)), block(256);
+#define L(TI, TO) hipLaunchKernelGGL((cast_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, (TO*)y, (long)n, scale)
+    if (in_dtype == AVSR_F32 && out_dtype == AVSR_BF16) L(float, bf16_t);
+    else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_F32) L(bf16_t, float);
+    else if (in_dtype == AVSR_F32 && out_dtype == AVSR_F32) L(float, float);
+    else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_BF16) L(bf16_t, bf16_t);
+    else return AVSR_EINVAL;
+#undef L
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_transpose(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, int64_t ldx, int64_t sx,
+                              void* y, int64_t ldy, int64_t sy, int64_t batch, int64_t R, int64_t C, float scale) {
+    if (!x || !y || batch <= 0 || R <= 0 || C <= 0 || batch > 65535) return AVSR_EINVAL;
+    if ((R + 31) / 32 > 65535) return AVSR_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32), (unsigned)batch), block(256);
+#define L(TI, TO) hipLaunchKernelGGL((transpose_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, (long)ldx, (long)sx, (TO*)y, \
+                                     (long)ldy, (long)sy, (int)R, (int)C, scale)
+    if (in_dtype == AVSR_F32 && out_dtype == AVSR_BF16) L(float, bf16_t);
+    else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_F32) L(bf16_t, float);
+    else if (in_dtype == AVSR_F32 && out_dtype == AVSR_F32) L(float, float);
+    else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_BF16) L(bf16_t, bf16_t);
+    else return AVSR_EINVAL;
+#undef L
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_colsum(avsr_stream_t stream, int dtype, const void* x, int64_t ld, int64_t M, int64_t N, float* out,
+                           int accumulate) {
+    if (!x || !out || M <= 0 || N <= 0) return AVSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((N + 63) / 64)), block(256);
+    if (dtype == AVSR_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)x, (long)ld, (int)M, (int)N, out, accumulate);
+    else if (dtype == AVSR_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, (long)ld, (int)M, (int)N, out, accumulate);
+    else return AVSR_EINVAL;
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_gelu_fwd(avsr_stream_t stream, int dtype, const void* x, void* y, int64_t n) {
+    if (!x || !y || n <= 0) return AVSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(grid_for(n, 256, 8192)), block(256);
+    if (dtype == AVSR_F32) hipLaunchKernelGGL(gelu_fwd_kernel<float>, grid, block, 0, s, (const float*)x, (float*)y, (long)n);
+    else if (dtype == AVSR_BF16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, (long)n);
+    else return AVSR_EINVAL;
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_gelu_bwd(avsr_stream_t stream, int dtype, const void* x, const void* dy, void* dx, int64_t n) {
+    if (!x || !dy || !dx || n <= 0) return AVSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(grid_for(n, 256, 8192)), block(256);
+    if (dtype == AVSR_F32) hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, block, 0, s, (const float*)x, (const float*)dy, (float*)dx, (long)n);
+    else if (dtype == AVSR_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, (long)n);
+    else return AVSR_EINVAL;
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_gated_residual_fwd(avsr_stream_t stream, int dtype, const void* x, const void* y, const float* gate,
+                                       void* out, int64_t n, float p_drop, uint64_t seed) {
+    if (!x || !y || !gate || !out || n <= 0 || p_drop < 0.f || p_drop >= 1.f) return AVSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(grid_for(n, 256, 4096)), block(256);
+    if (dtype == AVSR_F32) hipLaunchKernelGGL(gated_residual_fwd_kernel<float>, grid, block, 0, s, (const float*)x, (const float*)y, gate, (float*)out, (long)n, p_drop, seed);
+    else if (dtype == AVSR_BF16) hipLaunchKernelGGL(gated_residual_fwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, (const bf16_t*)y, gate, (bf16_t*)out, (long)n, p_drop, seed);
+    else return AVSR_EINVAL;
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_gated_residual_bwd(avsr_stream_t stream, int dtype, const void* dout, const void* y, const float* gate,
+                                       void* dy, float* dgate, int64_t n, float p_drop, uint64_t seed) {
+    if (!dout || !y || !gate || !dy || !dgate || n <= 0 || p_drop < 0.f || p_drop >= 1.f) return AVSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(grid_for(n, 256, 1024)), block(256);
+    if (dtype == AVSR_F32) hipLaunchKernelGGL(gated_residual_bwd_kernel<float>, grid, block, 0, s, (const float*)dout, (const float*)y, gate, (float*)dy, dgate, (long)n, p_drop, seed);
+    else if (dtype == AVSR_BF16) hipLaunchKernelGGL(gated_residual_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dout, (const bf16_t*)y, gate, (bf16_t*)dy, dgate, (long)n, p_drop, seed);
+    else return AVSR_EINVAL;
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_add3(avsr_stream_t stream, int dtype, const void* a, const void* b, const void* c, void* out, int64_t n) {
+    if (!a || !b || !out || n <= 0) return AVSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(grid_for(n, 256, 4096)), block(256);
+    if (dtype == AVSR_F32) hipLaunchKernelGGL(add3_kernel<float>, grid, block, 0, s, (const float*)a, (const float*)b, (const float*)c, (float*)out, (long)n);
+    else if (dtype == AVSR_BF16) hipLaunchKernelGGL(add3_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c, (bf16_t*)out, (long)n);
+    else return AVSR_EINVAL;
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_sumsq_accumulate(avsr_stream_t stream, const float* x, int64_t n, float* out) {
+    if (!x || !out || n <= 0) return AVSR_EINVAL;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_clip_scale(avsr_stream_t stream, const float* sumsq, float max_norm, float* scale, float* norm_out) {
+    if (!sumsq || !scale) return AVSR_EINVAL;
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, scale, norm_out);
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_adamw_step(avsr_stream_t stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                               void* bf16_shadow, int64_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int64_t step, const float* grad_scale) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return AVSR_EINVAL;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, (bf16_t*)bf16_shadow, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    return avsr_launch_status();
+}
+
+extern "C" const char* avsr_version(void) { return "avsr_hip 0.1 (gfx950)"; }

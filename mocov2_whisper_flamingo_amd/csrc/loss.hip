@@ -1,0 +1,275 @@
+// Head losses over the [rows, V] logits: row log-sum-exp, label-smoothed cross
+// entropy, CTC (alpha/beta recursions in log space) and one fused pass that
+// writes d(loss)/d(logits) for CTC + CE, plus the greedy arg-max.
+// All of it is HBM bound on the logits tensor; every kernel reads a logits
+// row once with one 256-thread block per row.
+#include "common.h"
+
+// lse[row] = log sum_v exp(x[row, v]); also sumx[row] = sum_v x[row, v].
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ x, long ld, int V, float* __restrict__ lse,
+                                                      float* __restrict__ sumx) {
+    __shared__ float red[16];
+    const float* xr = x + (long)blockIdx.x * ld;
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, xr[v]);
+    mx = block_max(mx, red);
+    float s = 0.f, sx = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) { const float a = xr[v]; s += __expf(a - mx); sx += a; }
+    s = block_sum(s, red);
+    sx = block_sum(sx, red);
+    if (threadIdx.x == 0) { lse[blockIdx.x] = mx + __logf(s); if (sumx) sumx[blockIdx.x] = sx; }
+}
+
+// Label-smoothed CE, mean over non-ignored targets (train.py:103-128).  Rows are
+// (b, t) with t < t_ce; target of row (b,t) is targets[b*ldt + t].  One block.
+// out[0] = loss, out[1] = number of non-ignored targets.
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ x, long ld, int V, const float* __restrict__ lse,
+                                                        const float* __restrict__ sumx, const int64_t* __restrict__ targets,
+                                                        long ldt, int B, int T, int t_ce, float eps, int ignore_index,
+                                                        float* __restrict__ out) {
+    __shared__ float red[16];
+    float acc = 0.f, cnt = 0.f;
+    for (int i = threadIdx.x; i < B * t_ce; i += 256) {
+        const int b = i / t_ce, t = i - b * t_ce;
+        const long tg = targets[(long)b * ldt + t];
+        if (tg == ignore_index) continue;
+        const long row = (long)b * T + t;
+        const float nll = lse[row] - x[row * ld + tg];
+        const float smooth = lse[row] - sumx[row] / (float)V;
+        acc += (1.f - eps) * nll + eps * smooth;
+        cnt += 1.f;
+    }
+    acc = block_sum(acc, red);
+    cnt = block_sum(cnt, red);
+    if (threadIdx.x == 0) { out[0] = cnt > 0.f ? acc / cnt : 0.f; out[1] = cnt; }
+}
+
+// ------------------------------------------------------------------ CTC ----
+__device__ __forceinline__ float lse2(float a, float b) {
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    const float m = fmaxf(a, b);
+    return m + __logf(__expf(a - m) + __expf(b - m));
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) { return lse2(lse2(a, b), c); }
+
+// One block per batch item.  Extended label sequence l' = (blank, y1, blank,
+// ..., yL, blank), S = 2L+1 states.  alpha/beta are [B, T, Smax] in global
+// memory; time steps are separated by block barriers.  nll[b] = -log p(y|x);
+// with zero_infinity an infeasible alignment (nll = inf) is reported as inf
+// here and zeroed by the consumers.
+__global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __restrict__ x, long ld, const float* __restrict__ lse,
+                                                             const int64_t* __restrict__ targets, long ldt,
+                                                             const int64_t* __restrict__ in_len, const int64_t* __restrict__ tg_len,
+                                                             float* __restrict__ alpha, float* __restrict__ beta,
+                                                             float* __restrict__ nll, int T, int Smax, int blank) {
+    const int b = blockIdx.x;
+    const int Tb = (int)min((long)in_len[b], (long)T);
+    const int L = (int)tg_len[b];
+    const int S = 2 * L + 1;
+    float* al = alpha + (long)b * T * Smax;
+    float* be = beta + (long)b * T * Smax;
+    const int64_t* tg = targets + (long)b * ldt;
+    auto label = [&](int s) -> long { return (s & 1) ? tg[s >> 1] : (long)blank; };
+    auto lp = [&](int t, long c) -> float { const long row = (long)b * T + t; return x[row * ld + c] - lse[row]; };
+    if (Tb <= 0 || S > Smax) { if (threadIdx.x == 0) nll[b] = INFINITY; return; }
+    for (int s = threadIdx.x; s < S; s += 256)
+        al[s] = (s == 0 || s == 1) ? lp(0, label(s)) : -INFINITY;
+    __syncthreads();
+    for (int t = 1; t < Tb; ++t) {
+        for (int s = threadIdx.x; s < S; s += 256) {
+            const long c = label(s);
+            const float a0 = al[(long)(t - 1) * Smax + s];
+            const float a1 = s >= 1 ? al[(long)(t - 1) * Smax + s - 1] : -INFINITY;
+            const float a2 = (s >= 2 && c != blank && label(s - 2) != c) ? al[(long)(t - 1) * Smax + s - 2] : -INFINITY;
+            al[(long)t * Smax + s] = lse3(a0, a1, a2) + lp(t, c);
+        }
+        __syncthreads();
+    }
+    for (int s = threadIdx.x; s < S; s += 256)
+        be[(long)(Tb - 1) * Smax + s] = (s == S - 1 || s == S - 2) ? lp(Tb - 1, label(s)) : -INFINITY;
+    __syncthreads();
+    for (int t = Tb - 2; t >= 0; --t) {
+        for (int s = threadIdx.x; s < S; s += 256) {
+            const long c = label(s);
+            const float b0 = be[(long)(t + 1) * Smax + s];
+            const float b1 = s + 1 < S ? be[(long)(t + 1) * Smax + s + 1] : -INFINITY;
+            const float b2 = (s + 2 < S && c != blank && label(s + 2) != c) ? be[(long)(t + 1) * Smax + s + 2] : -INFINITY;
+            be[(long)t * Smax + s] = lse3(b0, b1, b2) + lp(t, c);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float e0 = al[(long)(Tb - 1) * Smax + S - 1];
+        const float e1 = S >= 2 ? al[(long)(Tb - 1) * Smax + S - 2] : -INFINITY;
+        nll[b] = -lse2(e0, e1);
+    }
+}
+
+// loss_ctc = mean_b( zero_inf(nll[b]) / max(tg_len[b], 1) )   (reduction='mean')
+__global__ void ctc_reduce_kernel(const float* __restrict__ nll, const int64_t* __restrict__ tg_len, int B,
+                                  float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float v = nll[b];
+            if (v != INFINITY && v == v) s += v / (float)max((long)tg_len[b], 1L);
+        }
+        out[0] = s / (float)B;
+    }
+}
+
+// d(w_ctc*ctc + w_ce*ce)/d(logits) for row (b,t): dense part in one sweep.
+//   CTC: g_ctc * (p_v - occ_tv)              for t < in_len[b], feasible b
+//   CE : g_ce  * (p_v - eps/V - (1-eps)[v==target])   for t < t_ce, target kept
+// The sparse CTC occupancy term is subtracted afterwards by ctc_grad_sparse.
+template <typename TG>
+__global__ __launch_bounds__(256) void head_grad_dense_kernel(const float* __restrict__ x, long ld, int V,
+                                                              const float* __restrict__ lse, const int64_t* __restrict__ targets,
+                                                              long ldt, const int64_t* __restrict__ in_len,
+                                                              const int64_t* __restrict__ tg_len, const float* __restrict__ nll,
+                                                              const float* __restrict__ ce_out, int B, int T, int t_ce, float eps,
+                                                              int ignore_index, float w_ctc, float w_ce,
+                                                              const float* __restrict__ upstream, TG* __restrict__ dx, long lddx) {
+    const long row = blockIdx.x;
+    const int b = (int)(row / T), t = (int)(row - (long)b * T);
+    const float up = upstream ? upstream[0] : 1.f;
+    float gctc = 0.f;
+    if (t < in_len[b] && nll[b] != INFINITY && nll[b] == nll[b])
+        gctc = up * w_ctc / ((float)B * (float)max((long)tg_len[b], 1L));
+    float gce = 0.f; long tg = -1;
+    if (t < t_ce) {
+        tg = targets[(long)b * ldt + t];
+        if (tg != ignore_index && ce_out[1] > 0.f) gce = up * w_ce / ce_out[1]; else tg = -1;
+    }
+    const float* xr = x + row * ld;
+    TG* dr = dx + row * lddx;
+    const float L = lse[row];
+    const float gs = gctc + gce, c0 = gce * eps / (float)V, c1 = gce * (1.f - eps);
+    for (int v = threadIdx.x; v < V; v += 256) {
+        float g = gs * __expf(xr[v] - L) - c0;
+        if (v == tg) g -= c1;
+        dr[v] = from_f32<TG>(g);
+    }
+}
+
+// Sparse CTC term: dx[b,t,l'_s] -= g_ctc * exp(alpha + beta + nll - lp).  Several
+// states can carry the same label, so one thread per (b,t) walks the states
+// serially (S <= 2*448+1) - no atomics, deterministic.
+template <typename TG>
+__global__ __launch_bounds__(64) void ctc_grad_sparse_kernel(const float* __restrict__ x, long ld, const float* __restrict__ lse,
+                                                            const int64_t* __restrict__ targets, long ldt,
+                                                            const int64_t* __restrict__ in_len, const int64_t* __restrict__ tg_len,
+                                                            const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                            const float* __restrict__ nll, int B, int T, int Smax, int blank,
+                                                            float w_ctc, const float* __restrict__ upstream, TG* __restrict__ dx,
+                                                            long lddx) {
+    const long row = (long)blockIdx.x * 64 + threadIdx.x;
+    if (row >= (long)B * T) return;
+    const int b = (int)(row / T), t = (int)(row - (long)b * T);
+    if (t >= in_len[b] || t >= T) return;
+    const float nl = nll[b];
+    if (nl == INFINITY || nl != nl) return;
+    const int L = (int)tg_len[b], S = 2 * L + 1;
+    const float up = upstream ? upstream[0] : 1.f;
+    const float g = up * w_ctc / ((float)B * (float)max((long)L, 1L));
+    const int64_t* tg = targets + (long)b * ldt;
+    const float* al = alpha + ((long)b * T + t) * Smax;
+    const float* be = beta + ((long)b * T + t) * Smax;
+    const float Lr = lse[row];
+    TG* dr = dx + row * lddx;
+    for (int s = 0; s < S; ++s) {
+        const long c = (s & 1) ? tg[s >> 1] : (long)blank;
+        const float ab = al[s] + be[s];
+        if (ab == -INFINITY) continue;
+        const float lpv = x[row * ld + c] - Lr;
+        const float occ = __expf(ab + nl - lpv);
+        dr[c] = from_f32<TG>(to_f32<TG>(dr[c]) - g * occ);
+    }
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long ld, int V, int64_t* __restrict__ out) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const float* xr = x + (long)blockIdx.x * ld;
+    float best = -INFINITY; int idx = 0;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float a = xr[v];
+        if (a > best || (a != a && best == best)) { best = a; idx = v; }   // first max wins; NaN is a max, as in torch
+    }
+    bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float a = bv[threadIdx.x + o]; const int ia = bi[threadIdx.x + o];
+            const float c = bv[threadIdx.x]; const int ic = bi[threadIdx.x];
+            const bool a_nan = a != a, c_nan = c != c;
+            const bool take = (a_nan && !c_nan) || (a_nan == c_nan && (a > c || (a == c && ia < ic)) ) ||
+                              (a_nan && c_nan && ia < ic);
+            if (take) { bv[threadIdx.x] = a; bi[threadIdx.x] = ia; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = bi[0];
+}
+
+// --------------------------------------------------------------- host ------
+// Workspace layout (floats): lse[rows] | sumx[rows] | nll[B] | ce[2] | alpha[B*T*Smax] | beta[B*T*Smax]
+extern "C" int64_t avsr_head_loss_workspace_floats(int64_t B, int64_t T, int64_t max_target_len) {
+    const int64_t Smax = 2 * max_target_len + 1;
+    return 2 * B * T + B + 2 + 2 * B * T * Smax;
+}
+
+extern "C" int avsr_head_loss_fwd(avsr_stream_t stream, const float* logits, int64_t ld, int64_t B, int64_t T, int64_t V,
+                                  const int64_t* targets, int64_t ldt, int64_t max_target_len, const int64_t* input_lengths,
+                                  const int64_t* target_lengths, float label_smoothing, int64_t ignore_index,
+                                  int64_t blank, float* ws, float* out3) {
+    if (!logits || !targets || !input_lengths || !target_lengths || !ws || !out3) return AVSR_EINVAL;
+    if (B <= 0 || T <= 0 || V <= 0 || max_target_len <= 0 || max_target_len > ldt) return AVSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t rows = B * T, Smax = 2 * max_target_len + 1;
+    float* lse = ws; float* sumx = lse + rows; float* nll = sumx + rows; float* ce = nll + B;
+    float* alpha = ce + 2; float* beta = alpha + rows * Smax;
+    const int t_ce = (int)(T < max_target_len ? T : max_target_len);
+    hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, (long)ld, (int)V, lse, sumx);
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, logits, (long)ld, (int)V, lse, sumx, targets, (long)ldt,
+                       (int)B, (int)T, t_ce, label_smoothing, (int)ignore_index, ce);
+    hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3((unsigned)B), dim3(256), 0, s, logits, (long)ld, lse, targets, (long)ldt,
+                       input_lengths, target_lengths, alpha, beta, nll, (int)T, (int)Smax, (int)blank);
+    hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(64), 0, s, nll, target_lengths, (int)B, out3);
+    // out3 = {ctc, ce, n_ce_targets}: copy ce[0], ce[1] behind the ctc value
+    if (hipMemcpyAsync(out3 + 1, ce, 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_EHIP;
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_head_loss_bwd(avsr_stream_t stream, int grad_dtype, const float* logits, int64_t ld, int64_t B,
+                                  int64_t T, int64_t V, const int64_t* targets, int64_t ldt, int64_t max_target_len,
+                                  const int64_t* input_lengths, const int64_t* target_lengths, float label_smoothing,
+                                  int64_t ignore_index, int64_t blank, const float* ws, float w_ctc, float w_ce,
+                                  const float* upstream, void* dlogits, int64_t lddx) {
+    if (!logits || !targets || !input_lengths || !target_lengths || !ws || !dlogits) return AVSR_EINVAL;
+    if (B <= 0 || T <= 0 || V <= 0 || max_target_len <= 0 || max_target_len > ldt) return AVSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t rows = B * T, Smax = 2 * max_target_len + 1;
+    const float* lse = ws; const float* nll = lse + 2 * rows; const float* ce = nll + B;
+    const float* alpha = ce + 2; const float* beta = alpha + rows * Smax;
+    const int t_ce = (int)(T < max_target_len ? T : max_target_len);
+#define RUN(TG)                                                                                                          \
+    hipLaunchKernelGGL(head_grad_dense_kernel<TG>, dim3((unsigned)rows), dim3(256), 0, s, logits, (long)ld, (int)V, lse, \
+                       targets, (long)ldt, input_lengths, target_lengths, nll, ce, (int)B, (int)T, t_ce, label_smoothing,\
+                       (int)ignore_index, w_ctc, w_ce, upstream, (TG*)dlogits, (long)lddx);                              \
+    hipLaunchKernelGGL(ctc_grad_sparse_kernel<TG>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, logits, (long)ld, \
+                       lse, targets, (long)ldt, input_lengths, target_lengths, alpha, beta, nll, (int)B, (int)T,         \
+                       (int)Smax, (int)blank, w_ctc, upstream, (TG*)dlogits, (long)lddx)
+    if (grad_dtype == AVSR_F32) { RUN(float); }
+    else if (grad_dtype == AVSR_BF16) { RUN(bf16_t); }
+    else return AVSR_EINVAL;
+#undef RUN
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_argmax_rows(avsr_stream_t stream, const float* x, int64_t ld, int64_t rows, int64_t V, int64_t* out) {
+    if (!x || !out || rows <= 0 || V <= 0) return AVSR_EINVAL;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, (long)ld, (int)V, out);
+    return avsr_launch_status();
+}

@@ -1,0 +1,277 @@
+// Row-wise LayerNorm (forward / backward) with wave64 shuffle reductions, and
+// the batch-norm statistics / apply kernels of the visual trunk.
+#include "common.h"
+
+// One wave per row.  Each lane owns columns lane*4 + 256*i (float4 / bf16x4
+// chunks), so a wave reads a row as contiguous 1 KiB (fp32) segments and the
+// same lane sees the same columns in every row (used by the backward for the
+// dgamma / dbeta partial sums).
+#define LN_MAXV 8   // up to 8 chunks of 4 per lane -> D <= 2048
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float v[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float v[4]) {
+    const f32x4 x = *(const f32x4*)p; v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float v[4]) {
+    const bf16x4 x = *(const bf16x4*)p; v[0] = (float)x[0]; v[1] = (float)x[1]; v[2] = (float)x[2]; v[3] = (float)x[3];
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float v[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float v[4]) {
+    *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float v[4]) {
+    *(bf16x4*)p = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict__ x, long ldx, TO* __restrict__ y, long ldy,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ add, int add_period,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const TI* xr = x + (long)row * ldx;
+    float v[LN_MAXV][4];
+    const int nch = D >> 2;   // chunks of 4
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) { load4<TI>(xr + c * 4, v[i]); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) { if (mean_out) mean_out[row] = mean; if (rstd_out) rstd_out[row] = rstd; }
+    TO* yr = y + (long)row * ldy;
+    const float* ar = add ? add + (long)(row % add_period) * D : nullptr;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float g[4], b[4], o[4];
+            load4<float>(gamma + c * 4, g);
+            load4<float>(beta + c * 4, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            if (ar) { float a[4]; load4<float>(ar + c * 4, a);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += a[e]; }
+            store4<TO>(yr + c * 4, o);
+        }
+    }
+}
+
+// Backward: dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); dgamma +=
+// dy*xhat, dbeta += dy.  Each wave walks rows row0, row0+stride, ... and keeps its
+// dgamma/dbeta partials in registers; one atomic per column per wave at the end.
+template <typename TX, typename TG>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TG* __restrict__ dy, long lddy, const TX* __restrict__ x, long ldx,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, TG* __restrict__ dx, long lddx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nw = gridDim.x * 4;
+    const int nch = D >> 2;
+    float dg[LN_MAXV][4], db[LN_MAXV][4], g[LN_MAXV][4];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; g[i][e] = 0.f; }
+        if (c < nch) load4<float>(gamma + c * 4, g[i]);
+    }
+    for (int row = wid; row < rows; row += nw) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[LN_MAXV][4], gy[LN_MAXV][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                float xv[4], dv[4];
+                load4<TX>(x + (long)row * ldx + c * 4, xv);
+                load4<TG>(dy + (long)row * lddy + c * 4, dv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xv[e] - mu) * rs;
+                    gy[i][e] = dv[e] * g[i][e];
+                    s1 += gy[i][e];
+                    s2 += gy[i][e] * xh[i][e];
+                    dg[i][e] += dv[e] * xh[i][e];
+                    db[i][e] += dv[e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2);
+                store4<TG>(dx + (long)row * lddx + c * 4, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(dgamma + c * 4 + e, dg[i][e]);
+                atomicAdd(dbeta + c * 4 + e, db[i][e]);
+            }
+        }
+    }
+}
+
+extern "C" int avsr_layernorm_fwd(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, int64_t ldx,
+                                  void* y, int64_t ldy, const float* gamma, const float* beta, const float* add,
+                                  int64_t add_period, float* mean, float* rstd, int64_t rows, int64_t D, float eps) {
+    if (!x || !y || !gamma || !beta || rows <= 0) return AVSR_EINVAL;
+    if (D % 4 || D > 64 * 4 * LN_MAXV || ldx % 4 || ldy % 4) return AVSR_EUNSUPPORTED;
+    if (add && add_period <= 0) return AVSR_EINVAL;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define L(TI, TO) hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, (long)ldx, (TO*)y, \
+                                     (long)ldy, gamma, beta, add, (int)add_period, mean, rstd, (int)rows, (int)D, eps)
+    if (in_dtype == AVSR_F32 && out_dtype == AVSR_F32) L(float, float);
+    else if (in_dtype == AVSR_F32 && out_dtype == AVSR_BF16) L(float, bf16_t);
+    else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_BF16) L(bf16_t, bf16_t);
+    else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_F32) L(bf16_t, float);
+    else return AVSR_EINVAL;
+#undef L
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_layernorm_bwd(avsr_stream_t stream, int x_dtype, int g_dtype, const void* dy, int64_t lddy,
+                                  const void* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
+                                  void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int64_t D) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return AVSR_EINVAL;
+    if (D % 4 || D > 64 * 4 * LN_MAXV || ldx % 4 || lddy % 4 || lddx % 4) return AVSR_EUNSUPPORTED;
+    long nb = (rows + 3) / 4;
+    if (nb > 256) nb = 256;
+    dim3 grid((unsigned)nb), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define L(TX, TG) hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TG>), grid, block, 0, s, (const TG*)dy, (long)lddy, (const TX*)x, \
+                                     (long)ldx, gamma, mean, rstd, (TG*)dx, (long)lddx, dgamma, dbeta, (int)rows, (int)D)
+    if (x_dtype == AVSR_F32 && g_dtype == AVSR_F32) L(float, float);
+    else if (x_dtype == AVSR_F32 && g_dtype == AVSR_BF16) L(float, bf16_t);
+    else if (x_dtype == AVSR_BF16 && g_dtype == AVSR_BF16) L(bf16_t, bf16_t);
+    else if (x_dtype == AVSR_BF16 && g_dtype == AVSR_F32) L(bf16_t, float);
+    else return AVSR_EINVAL;
+#undef L
+    return avsr_launch_status();
+}
+
+// ------------------------------------------------------------ batch norm ---
+// Turn per-channel sums into the affine (scale, shift) the next kernel applies,
+// and update the running statistics the way nn.BatchNorm does in training mode
+// (momentum update with the UNBIASED variance).
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, float count,
+                                   const float* __restrict__ weight, const float* __restrict__ bias,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ scale, float* __restrict__ shift, int C, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = sum[c] / count;
+    float var = sumsq[c] / count - mean * mean;
+    var = fmaxf(var, 0.f);
+    const float sc = weight[c] * rsqrtf(var + eps);
+    scale[c] = sc;
+    shift[c] = bias[c] - mean * sc;
+    if (running_mean) {
+        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+}
+
+// Eval-mode fold: scale = w / sqrt(running_var + eps), shift = b - running_mean*scale.
+__global__ void bn_fold_kernel(const float* __restrict__ weight, const float* __restrict__ bias,
+                               const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                               float* __restrict__ scale, float* __restrict__ shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = weight[c] * rsqrtf(running_var[c] + eps);
+    scale[c] = sc;
+    shift[c] = bias[c] - running_mean[c] * sc;
+}
+
+// y = act(x*scale[c] + shift[c] (+ residual)) over an NHWC tensor [rows, C];
+// 8 (bf16) or 4 (f32) channels per thread, grid-stride.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       long n4, int C, int relu) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int c = (int)((i * 4) % C);
+        float v[4], sc[4], sh[4];
+        load4<T>(x + i * 4, v);
+        load4<float>(scale + c, sc);
+        load4<float>(shift + c, sh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+        if (res) { float r[4]; load4<T>(res + i * 4, r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r[e]; }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f); }
+        store4<T>(y + i * 4, v);
+    }
+}
+
+extern "C" int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq, double count,
+                                const float* weight, const float* bias, float* running_mean, float* running_var,
+                                float* scale, float* shift, int64_t C, float eps, float momentum) {
+    if (!sum || !sumsq || !weight || !bias || !scale || !shift || C <= 0 || count <= 0) return AVSR_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sum, sumsq,
+                       (float)count, weight, bias, running_mean, running_var, scale, shift, (int)C, eps, momentum);
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_bn_fold(avsr_stream_t stream, const float* weight, const float* bias, const float* running_mean,
+                            const float* running_var, float* scale, float* shift, int64_t C, float eps) {
+    if (!weight || !bias || !running_mean || !running_var || !scale || !shift || C <= 0) return AVSR_EINVAL;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, bias,
+                       running_mean, running_var, scale, shift, (int)C, eps);
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_bn_apply(avsr_stream_t stream, int dtype, const void* x, const void* residual, void* y,
+                             const float* scale, const float* shift, int64_t rows, int64_t C, int relu) {
+    if (!x || !y || !scale || !shift || rows <= 0 || C <= 0) return AVSR_EINVAL;
+    if (C % 4) return AVSR_EUNSUPPORTED;
+    const long n4 = rows * C / 4;
+    long nb = (n4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == AVSR_F32)
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)x, (const float*)residual,
+                           (float*)y, scale, shift, n4, (int)C, relu);
+    else if (dtype == AVSR_BF16)
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)x,
+                           (const bf16_t*)residual, (bf16_t*)y, scale, shift, n4, (int)C, relu);
+    else return AVSR_EINVAL;
+    return avsr_launch_status();
+}

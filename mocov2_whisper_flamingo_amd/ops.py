@@ -1,0 +1,354 @@
+"""Tensor-level wrappers over the C ABI (no autograd here): each function takes
+torch tensors that already live on the GPU, checks what the kernels assume,
+and launches on torch's current stream.  torch only provides device memory and
+the stream.
+"""
+import ctypes
+import torch
+
+from . import _lib
+from ._lib import F32, BF16, ACT_NONE, ACT_GELU, ACT_RELU, ACT_RELU_AFTER_RESIDUAL, GemmDesc, check
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}") from None
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.AvsrHipError("tensor is not on the GPU - there is no CPU path in this package")
+
+
+def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NONE, residual=None,
+            res_period=0, gate=None, alpha=1.0, col_stats=None, conv=None, M=None):
+    """out[m,n] = epi(sum_k a[m,k] b[n,k]).  a: [M,K] or [batch,M,K]; b: [N,K] or [batch,N,K].
+    conv = (H, W, C, KH, KW, stride, pad, OH, OW): a is an NHWC image batch and M = n_img*OH*OW."""
+    lib = _lib.load()
+    _need_cuda(a, b, out, bias, scale, residual, gate)
+    d = GemmDesc()
+    batched = b.dim() == 3
+    N, K = b.shape[-2], b.shape[-1]
+    if conv is not None:
+        H, W, C, KH, KW, stride, pad, OH, OW = conv
+        if not a.is_contiguous():
+            raise ValueError("conv input must be contiguous NHWC")
+        d.conv.enabled, d.conv.H, d.conv.W, d.conv.C = 1, H, W, C
+        d.conv.KH, d.conv.KW, d.conv.stride, d.conv.pad, d.conv.OH, d.conv.OW = KH, KW, stride, pad, OH, OW
+        Mv = a.numel() // (H * W * C) * OH * OW
+        lda, sA, batch = 0, 0, 1
+    else:
+        if a.stride(-1) != 1 or b.stride(-1) != 1:
+            raise ValueError("gemm_nt operands must be K-contiguous")
+        Mv = a.shape[-2] if M is None else M
+        lda = a.stride(-2)
+        batch = a.shape[0] if a.dim() == 3 else 1
+        sA = a.stride(0) if a.dim() == 3 else 0
+        if a.shape[-1] != K:
+            raise ValueError(f"K mismatch {a.shape} vs {b.shape}")
+    if batched and b.shape[0] != batch:
+        raise ValueError("batch mismatch")
+    odt = out_dtype if out_dtype is not None else (out.dtype if out is not None else a.dtype)
+    if out is None:
+        shape = (batch, Mv, N) if (a.dim() == 3 and conv is None) else (Mv, N)
+        out = torch.empty(shape, dtype=odt, device=a.device)
+    if out.stride(-1) != 1:
+        raise ValueError("out must be row-major")
+    d.in_dtype, d.out_dtype = _dt(a), _DT[out.dtype]
+    if b.dtype != a.dtype:
+        raise TypeError("a and b dtypes differ")
+    d.M, d.N, d.K = Mv, N, K
+    d.A, d.lda, d.B, d.ldb = a.data_ptr(), lda, b.data_ptr(), b.stride(-2)
+    d.C, d.ldc = out.data_ptr(), out.stride(-2)
+    d.batch, d.strideA = batch, sA
+    d.strideB = b.stride(0) if batched else 0
+    d.strideC = out.stride(0) if out.dim() == 3 else 0
+    d.alpha = alpha
+    d.scale, d.bias, d.act = _p(scale), _p(bias), act
+    if residual is not None:
+        if residual.dtype != out.dtype or residual.stride(-1) != 1:
+            raise ValueError("residual must match the output dtype and be row-major")
+        d.residual, d.ldr, d.res_period = residual.data_ptr(), residual.stride(-2), res_period
+    d.gate = _p(gate)
+    if col_stats is not None:
+        d.col_sum, d.col_sumsq = col_stats[0].data_ptr(), col_stats[1].data_ptr()
+    check(lib.avsr_gemm_nt(_stream(), ctypes.byref(d)), "avsr_gemm_nt")
+    return out
+
+
+def conv_nhwc(x, w, KH, KW, stride, pad, **kw):
+    """x: [N,H,W,C] contiguous; w: [Cout, KH*KW*C] -> [N,OH,OW,Cout]."""
+    n, H, W, C = x.shape
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    y = gemm_nt(x, w, conv=(H, W, C, KH, KW, stride, pad, OH, OW), **kw)
+    return y.view(n, OH, OW, w.shape[0])
+
+
+def layernorm_fwd(x, gamma, beta, *, out_dtype=None, add=None, save_stats=False, eps=1e-5):
+    lib = _lib.load()
+    _need_cuda(x, gamma, beta, add)
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    rows = x2.shape[0]
+    y = torch.empty((rows, D), dtype=out_dtype or x.dtype, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    period = add.shape[0] if add is not None else 0
+    check(lib.avsr_layernorm_fwd(_stream(), _dt(x2), _DT[y.dtype], x2.data_ptr(), x2.stride(0), y.data_ptr(), D,
+                                 gamma.data_ptr(), beta.data_ptr(), _p(add), period, _p(mean), _p(rstd), rows, D, eps),
+          "avsr_layernorm_fwd")
+    y = y.view(*x.shape[:-1], D)
+    return (y, mean, rstd) if save_stats else y
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
+    lib = _lib.load()
+    D = x.shape[-1]
+    x2, dy2 = x.reshape(-1, D), dy.reshape(-1, D)
+    dx = torch.empty_like(dy2)
+    check(lib.avsr_layernorm_bwd(_stream(), _dt(x2), _dt(dy2), dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0),
+                                 gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), D, dgamma.data_ptr(),
+                                 dbeta.data_ptr(), x2.shape[0], D), "avsr_layernorm_bwd")
+    return dx.view(dy.shape)
+
+
+def _bthd(t, H):
+    """[B,T,*] view whose last dim holds H heads of 64 starting at the view's offset."""
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise ValueError("attention operands must be [B,T,H*64] views with unit inner stride")
+    if t.stride(0) != t.shape[1] * t.stride(1):
+        raise ValueError("attention operands must have batch stride = T * row stride")
+    return t.stride(1)
+
+
+def attn_fwd(q, k, v, H, *, key_mask=None, scale=1.0, use_mfma=False, save_lse=False, p_drop=0.0, seed=0):
+    """q: [B,Tq,H*64] view, k/v: [B,Tk,H*64] views (may be column slices of a fused QKV buffer)."""
+    lib = _lib.load()
+    _need_cuda(q, k, v, key_mask)
+    B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
+    o = torch.empty((B, Tq, H * 64), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device) if save_lse else None
+    if key_mask is not None and (key_mask.dtype != torch.uint8 or not key_mask.is_contiguous()):
+        raise ValueError("key_mask must be contiguous uint8 [B,Tk]")
+    check(lib.avsr_attn_fwd(_stream(), _dt(q), int(use_mfma), q.data_ptr(), _bthd(q, H), k.data_ptr(), _bthd(k, H),
+                            v.data_ptr(), _bthd(v, H), o.data_ptr(), H * 64, _p(key_mask), _p(lse), B, H, Tq, Tk, 64,
+                            scale, p_drop, seed), "avsr_attn_fwd")
+    return (o, lse) if save_lse else o
+
+
+def attn_bwd(q, k, v, o, do, lse, H, *, key_mask=None, scale=1.0, p_drop=0.0, seed=0):
+    lib = _lib.load()
+    B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
+    dq = torch.empty((B, Tq, H * 64), dtype=q.dtype, device=q.device)
+    dk = torch.empty((B, Tk, H * 64), dtype=q.dtype, device=q.device)
+    dv = torch.empty((B, Tk, H * 64), dtype=q.dtype, device=q.device)
+    ws = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
+    do = do.contiguous()
+    check(lib.avsr_attn_bwd(_stream(), _dt(q), q.data_ptr(), _bthd(q, H), k.data_ptr(), _bthd(k, H), v.data_ptr(),
+                            _bthd(v, H), o.data_ptr(), _bthd(o, H), do.data_ptr(), _bthd(do, H), dq.data_ptr(), H * 64,
+                            dk.data_ptr(), H * 64, dv.data_ptr(), H * 64, _p(key_mask), lse.data_ptr(), ws.data_ptr(),
+                            B, H, Tq, Tk, 64, scale, p_drop, seed), "avsr_attn_bwd")
+    return dq, dk, dv
+
+
+def stem3d_fwd(video, weight, out_dtype, *, scale=None, shift=None, col_stats=None):
+    """video [B,T,3,H,W] fp32 contiguous -> NHWC [B*T,OH,OW,64]."""
+    lib = _lib.load()
+    _need_cuda(video, weight)
+    if video.dtype != torch.float32 or not video.is_contiguous() or weight.dtype != torch.float32:
+        raise ValueError("stem expects contiguous fp32 video and fp32 weight")
+    B, T, C, H, W = video.shape
+    if C != 3 or tuple(weight.shape) != (64, 3, 5, 3, 3):
+        raise ValueError("stem shape mismatch")
+    OH, OW = (H + 6 - 3) // 2 + 1, (W + 6 - 3) // 2 + 1
+    out = torch.empty((B * T, OH, OW, 64), dtype=out_dtype, device=video.device)
+    cs = col_stats or (None, None)
+    check(lib.avsr_stem3d_fwd(_stream(), _DT[out_dtype], video.data_ptr(), weight.contiguous().data_ptr(), out.data_ptr(),
+                              _p(scale), _p(shift), _p(cs[0]), _p(cs[1]), B, T, H, W), "avsr_stem3d_fwd")
+    return out
+
+
+def maxpool3x3s2(x, *, scale=None, shift=None):
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
+    check(lib.avsr_maxpool3x3s2(_stream(), _dt(x), x.data_ptr(), y.data_ptr(), _p(scale), _p(shift), N, H, W, C),
+          "avsr_maxpool3x3s2")
+    return y
+
+
+def avgpool_mask(x, lens, B, T, out_dtype):
+    """x NHWC [B*T,h,w,C] -> [B,T,C] mean over pixels, frames t>=lens[b] zeroed."""
+    lib = _lib.load()
+    n, h, w, C = x.shape
+    y = torch.empty((B, T, C), dtype=out_dtype, device=x.device)
+    check(lib.avsr_avgpool_mask_fwd(_stream(), _dt(x), _DT[out_dtype], x.data_ptr(), y.data_ptr(), _p(lens), B, T, h * w, C),
+          "avsr_avgpool_mask_fwd")
+    return y
+
+
+def bn_finalize(col_sum, col_sumsq, count, weight, bias, running_mean, running_var, scale, shift, eps=1e-5, momentum=0.1):
+    lib = _lib.load()
+    check(lib.avsr_bn_finalize(_stream(), col_sum.data_ptr(), col_sumsq.data_ptr(), float(count), weight.data_ptr(),
+                               bias.data_ptr(), _p(running_mean), _p(running_var), scale.data_ptr(), shift.data_ptr(),
+                               weight.numel(), eps, momentum), "avsr_bn_finalize")
+
+
+def bn_fold(weight, bias, running_mean, running_var, eps=1e-5):
+    lib = _lib.load()
+    scale, shift = torch.empty_like(weight), torch.empty_like(weight)
+    check(lib.avsr_bn_fold(_stream(), weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                           scale.data_ptr(), shift.data_ptr(), weight.numel(), eps), "avsr_bn_fold")
+    return scale, shift
+
+
+def bn_apply(x, scale, shift, *, residual=None, relu=True, out=None):
+    lib = _lib.load()
+    C = x.shape[-1]
+    y = out if out is not None else torch.empty_like(x)
+    check(lib.avsr_bn_apply(_stream(), _dt(x), x.data_ptr(), _p(residual), y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                            x.numel() // C, C, int(relu)), "avsr_bn_apply")
+    return y
+
+
+def head_loss_fwd(logits, targets, input_lengths, target_lengths, label_smoothing=0.1, ignore_index=-100, blank=0):
+    """logits fp32 [B,T,V] (row stride may exceed V).  Returns (out3, ws): out3 = [ctc, ce, n_ce]."""
+    lib = _lib.load()
+    B, T, V = logits.shape
+    if logits.dtype != torch.float32 or logits.stride(2) != 1 or logits.stride(0) != T * logits.stride(1):
+        raise ValueError("logits must be fp32 [B,T,V] with uniform row stride")
+    Lw = targets.shape[1]
+    nws = lib.avsr_head_loss_workspace_floats(B, T, Lw)
+    ws = torch.empty(nws, dtype=torch.float32, device=logits.device)
+    out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
+    check(lib.avsr_head_loss_fwd(_stream(), logits.data_ptr(), logits.stride(1), B, T, V, targets.data_ptr(),
+                                 targets.stride(0), Lw, input_lengths.data_ptr(), target_lengths.data_ptr(),
+                                 label_smoothing, ignore_index, blank, ws.data_ptr(), out3.data_ptr()), "avsr_head_loss_fwd")
+    return out3, ws
+
+
+def head_loss_bwd(logits, targets, input_lengths, target_lengths, ws, grad_dtype, *, label_smoothing=0.1,
+                  ignore_index=-100, blank=0, w_ctc=1.0, w_ce=1.0, upstream=None, ld_out=None):
+    lib = _lib.load()
+    B, T, V = logits.shape
+    ld = ld_out or V
+    buf = torch.empty((B * T, ld), dtype=grad_dtype, device=logits.device)
+    if ld > V:
+        buf[:, V:].zero_()
+    check(lib.avsr_head_loss_bwd(_stream(), _DT[grad_dtype], logits.data_ptr(), logits.stride(1), B, T, V,
+                                 targets.data_ptr(), targets.stride(0), targets.shape[1], input_lengths.data_ptr(),
+                                 target_lengths.data_ptr(), label_smoothing, ignore_index, blank, ws.data_ptr(), w_ctc,
+                                 w_ce, _p(upstream), buf.data_ptr(), ld), "avsr_head_loss_bwd")
+    return buf
+
+
+def argmax_rows(logits):
+    lib = _lib.load()
+    V = logits.shape[-1]
+    rows = logits.numel() // V if logits.is_contiguous() else logits.shape[0] * logits.shape[1]
+    ld = logits.stride(-2)
+    out = torch.empty(logits.shape[:-1], dtype=torch.int64, device=logits.device)
+    check(lib.avsr_argmax_rows(_stream(), logits.data_ptr(), ld, rows, V, out.data_ptr()), "avsr_argmax_rows")
+    return out
+
+
+def cast(x, dtype, scale=1.0):
+    lib = _lib.load()
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    if x.numel():
+        check(lib.avsr_cast(_stream(), _dt(x), _DT[dtype], x.data_ptr(), y.data_ptr(), x.numel(), scale), "avsr_cast")
+    return y
+
+
+def transpose2d(x, dtype=None, scale=1.0):
+    """[..., R, C] contiguous -> [..., C, R] contiguous (optionally converting dtype)."""
+    lib = _lib.load()
+    x = x.contiguous()
+    R, C = x.shape[-2], x.shape[-1]
+    batch = x.numel() // (R * C)
+    y = torch.empty((*x.shape[:-2], C, R), dtype=dtype or x.dtype, device=x.device)
+    check(lib.avsr_transpose(_stream(), _dt(x), _DT[y.dtype], x.data_ptr(), C, R * C, y.data_ptr(), R, R * C, batch, R, C,
+                             scale), "avsr_transpose")
+    return y
+
+
+def colsum(x, out=None, accumulate=False):
+    lib = _lib.load()
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+    check(lib.avsr_colsum(_stream(), _dt(x), x.data_ptr(), x.stride(0), M, N, out.data_ptr(), int(accumulate)), "avsr_colsum")
+    return out
+
+
+def gelu_fwd(x):
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    check(lib.avsr_gelu_fwd(_stream(), _dt(x), x.data_ptr(), y.data_ptr(), x.numel()), "avsr_gelu_fwd")
+    return y
+
+
+def gelu_bwd(x, dy):
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    check(lib.avsr_gelu_bwd(_stream(), _dt(x), x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel()), "avsr_gelu_bwd")
+    return dx
+
+
+def gated_residual_fwd(x, y, gate, p_drop=0.0, seed=0):
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    check(lib.avsr_gated_residual_fwd(_stream(), _dt(x), x.data_ptr(), y.data_ptr(), gate.data_ptr(), out.data_ptr(),
+                                      x.numel(), p_drop, seed), "avsr_gated_residual_fwd")
+    return out
+
+
+def gated_residual_bwd(dout, y, gate, dgate, p_drop=0.0, seed=0):
+    lib = _lib.load()
+    dy = torch.empty_like(dout)
+    check(lib.avsr_gated_residual_bwd(_stream(), _dt(dout), dout.data_ptr(), y.data_ptr(), gate.data_ptr(), dy.data_ptr(),
+                                      dgate.data_ptr(), dout.numel(), p_drop, seed), "avsr_gated_residual_bwd")
+    return dy
+
+
+def add3(a, b, c=None):
+    lib = _lib.load()
+    out = torch.empty_like(a)
+    check(lib.avsr_add3(_stream(), _dt(a), a.data_ptr(), b.data_ptr(), _p(c), out.data_ptr(), a.numel()), "avsr_add3")
+    return out
+
+
+def sumsq_accumulate(x, out):
+    lib = _lib.load()
+    check(lib.avsr_sumsq_accumulate(_stream(), x.data_ptr(), x.numel(), out.data_ptr()), "avsr_sumsq_accumulate")
+
+
+def clip_scale(sumsq, max_norm, scale, norm_out=None):
+    lib = _lib.load()
+    check(lib.avsr_clip_scale(_stream(), sumsq.data_ptr(), max_norm, scale.data_ptr(), _p(norm_out)), "avsr_clip_scale")
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, step, *, lr, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01,
+               grad_scale=None, bf16_shadow=None):
+    lib = _lib.load()
+    check(lib.avsr_adamw_step(_stream(), param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                              _p(bf16_shadow), param.numel(), lr, betas[0], betas[1], eps, weight_decay, step,
+                              _p(grad_scale)), "avsr_adamw_step")

@@ -1,0 +1,318 @@
+"""Per-kernel parity tests: every C-ABI entry point against a plain PyTorch fp32
+CPU computation of the same op.  Tolerances: fp32 kernels 1e-4 relative to the
+output scale, bf16 kernels 2e-2 (bf16 inputs are rounded BEFORE the reference
+is computed, so only accumulation order and output rounding differ)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mocov2_whisper_flamingo_amd import ops  # noqa: E402
+from tests.philox_ref import keep_mask  # noqa: E402
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+
+
+def tol(dtype):
+    return 2e-2 if dtype == torch.bfloat16 else 2e-4
+
+
+def rnd(gen, *shape, dtype=torch.float32, scale=1.0):
+    x = torch.randn(*shape, generator=gen) * scale
+    return x.to(dtype).float() if dtype == torch.bfloat16 else x
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 64), (128, 128, 128), (257, 1001, 512), (75, 2048, 520), (1, 64, 8)])
+def test_gemm_plain(dev, dtype, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a, b = rnd(g, M, K, dtype=dtype), rnd(g, N, K, dtype=dtype)
+    ref = a @ b.T
+    out = ops.gemm_nt(a.to(dev, dtype), b.to(dev, dtype), out_dtype=torch.float32)
+    assert rel_err(out, ref) < tol(dtype) * 0.5
+    out2 = ops.gemm_nt(a.to(dev, dtype), b.to(dev, dtype))
+    assert out2.dtype == dtype and rel_err(out2, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_asymmetric_identity(dev, dtype):
+    # A = I with an asymmetric B catches a transposed accumulator write
+    n = 160
+    a = torch.eye(n)
+    b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) - 100.0
+    out = ops.gemm_nt(a.to(dev, dtype), b.to(dev, dtype), out_dtype=torch.float32)
+    assert torch.equal(out.cpu(), b.T.contiguous())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_epilogue(dev, dtype):
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 333, 264, 192
+    a, b = rnd(g, M, K, dtype=dtype), rnd(g, N, K, dtype=dtype, scale=0.1)
+    bias, scale = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
+    res = torch.randn(M, N, generator=g)
+    gate = torch.tensor([0.7])
+    pre = (a @ b.T) * 0.5 * scale + bias
+    ref = res + math.tanh(0.7) * F.gelu(pre)
+    out = ops.gemm_nt(a.to(dev, dtype), b.to(dev, dtype), out_dtype=torch.float32, bias=bias.to(dev), scale=scale.to(dev),
+                      act=ops.ACT_GELU, residual=res.to(dev), gate=gate.to(dev), alpha=0.5)
+    assert rel_err(out, ref) < tol(dtype)
+    # periodic residual (positional table) + relu + column statistics
+    table = torch.randn(37, N, generator=g)
+    cs = torch.zeros(2, N, device=dev)
+    out = ops.gemm_nt(a.to(dev, dtype), b.to(dev, dtype), out_dtype=torch.float32, bias=bias.to(dev), act=ops.ACT_RELU,
+                      residual=table.to(dev), res_period=37, col_stats=(cs[0], cs[1]))
+    pre = a @ b.T + bias
+    ref = table[torch.arange(M) % 37] + F.relu(pre)
+    assert rel_err(out, ref) < tol(dtype)
+    assert rel_err(cs[0], pre.sum(0)) < 1e-3
+    assert rel_err(cs[1], (pre * pre).sum(0)) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_batched_strided(dev, dtype):
+    g = torch.Generator().manual_seed(4)
+    Bt, T, D, N = 3, 50, 64, 96
+    big = rnd(g, Bt, 200, D, dtype=dtype)         # use the first T rows of each batch item
+    w = rnd(g, N, D, dtype=dtype)
+    ref = big[:, :T] @ w.T
+    a = big.to(dev, dtype)[:, :T]
+    out = ops.gemm_nt(a, w.to(dev, dtype), out_dtype=torch.float32)
+    assert out.shape == (Bt, T, N) and rel_err(out, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("cfg", [
+    # n, H, W, C, Cout, KH, KW, stride, pad
+    (3, 25, 25, 64, 64, 3, 3, 1, 1),
+    (2, 25, 25, 128, 128, 3, 3, 2, 1),
+    (2, 13, 13, 256, 512, 1, 1, 2, 0),
+    (5, 7, 7, 64, 256, 1, 1, 1, 0),
+    (2, 1, 300, 80, 96, 1, 3, 1, 1),      # Whisper conv1 as a 1-row image
+    (2, 1, 300, 96, 96, 1, 3, 2, 1),      # Whisper conv2 (stride 2)
+])
+def test_conv_implicit_gemm(dev, dtype, cfg):
+    n, H, W, C, Co, KH, KW, s, p = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = rnd(g, n, C, H, W, dtype=dtype)
+    w = rnd(g, Co, C, KH, KW, dtype=dtype, scale=1.0 / math.sqrt(C * KH * KW))
+    bias = torch.randn(Co, generator=g)
+    ref = F.relu(F.conv2d(x, w, bias, stride=s, padding=p)).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev, dtype)
+    wd = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous().to(dev, dtype)
+    out = ops.conv_nhwc(xd, wd, KH, KW, s, p, out_dtype=torch.float32, bias=bias.to(dev), act=ops.ACT_RELU)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("idt,odt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                     (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("D", [384, 512, 768, 1280])
+def test_layernorm_fwd_bwd(dev, idt, odt, D):
+    g = torch.Generator().manual_seed(D)
+    rows = 77
+    x = rnd(g, rows, D, dtype=idt) * 2 + 0.3
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    pe = torch.randn(10, D, generator=g)
+    ref = F.layer_norm(x, (D,), gamma, beta) + pe[torch.arange(rows) % 10]
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev, idt), gamma.to(dev), beta.to(dev), out_dtype=odt, add=pe.to(dev),
+                                      save_stats=True)
+    assert rel_err(y, ref) < tol(odt)
+    if idt == odt:
+        xr = x.clone().requires_grad_(True)
+        gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        dy = rnd(g, rows, D, dtype=odt)
+        F.layer_norm(xr, (D,), gr, br).backward(dy)
+        dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        dx = ops.layernorm_bwd(dy.to(dev, odt), x.to(dev, idt), gamma.to(dev), mean, rstd, dg, db)
+        assert rel_err(dx, xr.grad) < tol(odt)
+        gt = 1e-3 if odt == torch.float32 else 1e-2
+        assert rel_err(dg, gr.grad) < gt and rel_err(db, br.grad) < gt
+
+
+def _attn_ref(q, k, v, H, mask, scale, keep=None, p=0.0):
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    qh = q.view(B, Tq, H, 64).transpose(1, 2)
+    kh = k.view(B, Tk, H, 64).transpose(1, 2)
+    vh = v.view(B, Tk, H, 64).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) * scale
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :].bool(), float("-inf"))
+    dead = torch.isinf(s).all(-1, keepdim=True)
+    pr = torch.softmax(s.masked_fill(dead, 0.0), -1).masked_fill(dead, 0.0)
+    if keep is not None:
+        pr = pr * keep / (1 - p)
+    return (pr @ vh).transpose(1, 2).reshape(B, Tq, H * 64)
+
+
+@pytest.mark.parametrize("Tq,Tk", [(1500, 1500), (75, 75), (130, 257)])
+def test_attn_mfma_fwd(dev, Tq, Tk):
+    g = torch.Generator().manual_seed(Tq)
+    B, H = 2, 3
+    qkv = rnd(g, B, max(Tq, Tk), 3 * H * 64, dtype=torch.bfloat16)
+    mask = None
+    if Tq == 75:
+        mask = torch.zeros(B, Tk, dtype=torch.uint8)
+        mask[0, 40:] = 1
+        mask[1, :] = 1      # every key masked: rows must come out as zeros
+    q, k, v = qkv[:, :Tq, :H * 64], qkv[:, :Tk, H * 64:2 * H * 64], qkv[:, :Tk, 2 * H * 64:]
+    ref = _attn_ref(q.contiguous(), k.contiguous(), v.contiguous(), H, mask, 0.125)
+    d = qkv.to(dev, torch.bfloat16)
+    dq = d[:, :Tq].contiguous() if Tq != Tk else d      # column slices of a fused QKV buffer stay views
+    dkv = d[:, :Tk].contiguous() if Tq != Tk else d
+    o, lse = ops.attn_fwd(dq[:, :, :H * 64], dkv[:, :, H * 64:2 * H * 64], dkv[:, :, 2 * H * 64:], H,
+                          key_mask=None if mask is None else mask.to(dev), scale=0.125, use_mfma=True, save_lse=True)
+    assert torch.isfinite(o.float()).all()
+    assert rel_err(o, ref) < 2e-2
+    if mask is None:
+        s = (q.view(B, Tq, H, 64).transpose(1, 2) @ k.reshape(B, Tk, H, 64).transpose(1, 2).transpose(-1, -2)) * 0.125
+        assert rel_err(lse, torch.logsumexp(s, -1)) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_attn_valu_fwd_bwd(dev, dtype, p):
+    g = torch.Generator().manual_seed(11)
+    B, H, Tq, Tk = 2, 2, 75, 70
+    q, k, v = (rnd(g, B, t, H * 64, dtype=dtype) for t in (Tq, Tk, Tk))
+    mask = torch.zeros(B, Tk, dtype=torch.uint8)
+    mask[0, 50:] = 1
+    seed = 0x1234ABCD5678
+    keep = torch.from_numpy(keep_mask(seed, (B, H, Tq, Tk), p)).float() if p > 0 else None
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, H, mask, 0.125, keep, p)
+    do = rnd(g, B, Tq, H * 64, dtype=dtype)
+    ref.backward(do)
+    qd, kd, vd = (t.to(dev, dtype) for t in (q, k, v))
+    o, lse = ops.attn_fwd(qd, kd, vd, H, key_mask=mask.to(dev), scale=0.125, save_lse=True, p_drop=p, seed=seed)
+    assert rel_err(o, ref) < tol(dtype)
+    dq, dk, dv = ops.attn_bwd(qd, kd, vd, o, do.to(dev, dtype), lse, H, key_mask=mask.to(dev), scale=0.125, p_drop=p,
+                              seed=seed)
+    assert rel_err(dq, qr.grad) < tol(dtype) * 2
+    assert rel_err(dk, kr.grad) < tol(dtype) * 2
+    assert rel_err(dv, vr.grad) < tol(dtype) * 2
+
+
+@pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
+def test_stem_pool_bn(dev, odt):
+    g = torch.Generator().manual_seed(5)
+    B, T, H, W = 2, 4, 32, 36
+    video = torch.randn(B, T, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 5, 3, 3, generator=g) * 0.1
+    bw, bb = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    rm, rv = torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5
+    conv = F.conv3d(video.permute(0, 2, 1, 3, 4), w, stride=(1, 2, 2), padding=(2, 3, 3))
+    # eval mode
+    ref = F.max_pool3d(F.relu(F.batch_norm(conv, rm, rv, bw, bb, False)), (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(B * T, ref.shape[3], ref.shape[4], 64)
+    sc, sh = ops.bn_fold(bw.to(dev), bb.to(dev), rm.to(dev), rv.to(dev))
+    y = ops.stem3d_fwd(video.to(dev), w.to(dev), odt, scale=sc, shift=sh)
+    out = ops.maxpool3x3s2(y)
+    assert out.shape == ref.shape and rel_err(out, ref) < tol(odt)
+    # training mode: raw conv + batch statistics, affine+relu inside the pool
+    rm2, rv2 = rm.clone(), rv.clone()
+    ref_t = F.max_pool3d(F.relu(F.batch_norm(conv, rm2, rv2, bw, bb, True)), (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    ref_t = ref_t.permute(0, 2, 3, 4, 1).reshape(B * T, ref.shape[1], ref.shape[2], 64)
+    cs = torch.zeros(2, 64, device=dev)
+    raw = ops.stem3d_fwd(video.to(dev), w.to(dev), odt, col_stats=(cs[0], cs[1]))
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    sc2, sh2 = torch.empty(64, device=dev), torch.empty(64, device=dev)
+    ops.bn_finalize(cs[0], cs[1], raw.numel() // 64, bw.to(dev), bb.to(dev), rmd, rvd, sc2, sh2)
+    out_t = ops.maxpool3x3s2(raw, scale=sc2, shift=sh2)
+    assert rel_err(out_t, ref_t) < tol(odt) * 2
+    assert rel_err(rmd, rm2) < 1e-3 and rel_err(rvd, rv2) < 1e-3
+    # bn_apply with residual
+    x = rnd(g, 50, 64, dtype=odt)
+    r = rnd(g, 50, 64, dtype=odt)
+    ya = ops.bn_apply(x.to(dev, odt), sc, sh, residual=r.to(dev, odt), relu=True)
+    assert rel_err(ya, F.relu(x * sc.cpu() + sh.cpu() + r)) < tol(odt)
+    # avgpool + mask
+    feat = rnd(g, B * T, 4, 4, 128, dtype=odt)
+    lens = torch.tensor([3, 4])
+    pooled = ops.avgpool_mask(feat.to(dev, odt), lens.to(dev), B, T, torch.float32)
+    refp = feat.mean((1, 2)).view(B, T, 128)
+    refp[0, 3:] = 0
+    assert rel_err(pooled, refp) < tol(odt)
+
+
+def test_head_loss(dev):
+    g = torch.Generator().manual_seed(9)
+    B, T, V, L = 3, 20, 501, 6
+    ld = 504
+    logits = torch.randn(B, T, V, generator=g) * 2
+    targets = torch.randint(1, V, (B, L), generator=g)
+    targets[1, 2] = targets[1, 1]                     # repeated label
+    tl = torch.tensor([6, 4, 5])
+    il = torch.tensor([20, 15, 4])                    # last one infeasible (5 labels in 4 frames) -> zero_infinity
+    lr = logits.clone().requires_grad_(True)
+    lp = F.log_softmax(lr, -1).transpose(0, 1)
+    ctc = F.ctc_loss(lp, targets, il, tl, blank=0, reduction="mean", zero_infinity=True)
+    ce = F.cross_entropy(lr[:, :L].reshape(-1, V), targets.reshape(-1), ignore_index=-100, label_smoothing=0.1)
+    (ctc + ce).backward()
+    buf = torch.zeros(B, T, ld, device=dev)
+    buf[..., :V] = logits.to(dev)
+    lg = buf[..., :V]
+    out3, ws = ops.head_loss_fwd(lg, targets.to(dev), il.to(dev), tl.to(dev))
+    o = out3.cpu()
+    assert abs(o[0] - ctc.item()) < 1e-4 * max(1, abs(ctc.item()))
+    assert abs(o[1] - ce.item()) < 1e-4 * max(1, abs(ce.item()))
+    d = ops.head_loss_bwd(lg, targets.to(dev), il.to(dev), tl.to(dev), ws, torch.float32, ld_out=ld)
+    assert rel_err(d.view(B, T, ld)[..., :V], lr.grad) < 1e-3
+    am = ops.argmax_rows(lg)
+    assert torch.equal(am.cpu(), logits.argmax(-1))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_elementwise(dev, dtype):
+    g = torch.Generator().manual_seed(1)
+    x = rnd(g, 70, 130, dtype=dtype)
+    xd = x.to(dev, dtype)
+    assert rel_err(ops.transpose2d(xd), x.T) < 1e-6
+    assert rel_err(ops.cast(xd, torch.float32, 2.0), x * 2) < 1e-6
+    assert rel_err(ops.colsum(xd), x.sum(0)) < 1e-3
+    assert rel_err(ops.gelu_fwd(xd), F.gelu(x)) < tol(dtype)
+    xr = x.clone().requires_grad_(True)
+    dy = rnd(g, 70, 130, dtype=dtype)
+    F.gelu(xr).backward(dy)
+    assert rel_err(ops.gelu_bwd(xd, dy.to(dev, dtype)), xr.grad) < tol(dtype)
+    y = rnd(g, 70, 130, dtype=dtype)
+    gate = torch.tensor([0.4])
+    seed, p = 77, 0.3
+    keep = torch.from_numpy(keep_mask(seed, (70, 130), p)).float()
+    ref = x + math.tanh(0.4) * y * keep / (1 - p)
+    out = ops.gated_residual_fwd(xd, y.to(dev, dtype), gate.to(dev), p, seed)
+    assert rel_err(out, ref) < tol(dtype)
+    dg = torch.zeros(1, device=dev)
+    dyk = ops.gated_residual_bwd(dy.to(dev, dtype), y.to(dev, dtype), gate.to(dev), dg, p, seed)
+    assert rel_err(dyk, math.tanh(0.4) * dy * keep / (1 - p)) < tol(dtype)
+    ref_dg = (1 - math.tanh(0.4) ** 2) * (dy * y * keep / (1 - p)).sum()
+    assert abs(dg.item() - ref_dg.item()) < 2e-2 * abs(ref_dg.item()) + 1e-2
+    assert rel_err(ops.add3(xd, y.to(dev, dtype), dy.to(dev, dtype)), x + y + dy) < tol(dtype)
+
+
+def test_adamw_and_clip(dev):
+    g = torch.Generator().manual_seed(2)
+    n = 10007
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 3
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01)
+    pd, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in (1, 2, 3):
+        ref_p.grad = gr.clone() * step
+        norm = torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        gd = (gr * step).to(dev)
+        ss, sc, nrm = torch.zeros(1, device=dev), torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        ops.sumsq_accumulate(gd, ss)
+        ops.clip_scale(ss, 1.0, sc, nrm)
+        assert abs(nrm.item() - norm.item()) < 1e-3 * norm.item()
+        ops.adamw_step(pd, gd, m, v, step, lr=1e-3, grad_scale=sc)
+    assert rel_err(pd, ref_p.data) < 1e-5
