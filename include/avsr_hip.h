@@ -78,7 +78,7 @@ typedef struct {
     float* col_sumsq;     /* [N] or NULL */
     struct {
         int32_t enabled;
-        int32_t H, W, C, KH, KW, stride, pad, OH, OW;
+        int32_t H, W, C, KH, KW, stride, pad_h, pad_w, OH, OW;
     } conv;
 } avsr_gemm_t;
 
@@ -141,8 +141,8 @@ int avsr_attn_bwd(avsr_stream_t stream, int dtype, const void* Q, int64_t ldq, c
 int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float* video, const float* weight, void* out,
                     const float* scale, const float* shift, float* col_sum, float* col_sumsq, int64_t B,
                     int64_t T, int64_t H, int64_t W);
-int avsr_maxpool3x3s2(avsr_stream_t stream, int dtype, const void* x, void* y, const float* scale,
-                      const float* shift, int64_t N, int64_t H, int64_t W, int64_t C);
+int avsr_maxpool3x3s2(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y,
+                      const float* scale, const float* shift, int64_t N, int64_t H, int64_t W, int64_t C);
 int avsr_avgpool_mask_fwd(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y,
                           const int64_t* lens, int64_t B, int64_t T, int64_t HW, int64_t C);
 int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq, double count,
@@ -150,7 +150,8 @@ int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq,
                      float* scale, float* shift, int64_t C, float eps, float momentum);
 int avsr_bn_fold(avsr_stream_t stream, const float* weight, const float* bias, const float* running_mean,
                  const float* running_var, float* scale, float* shift, int64_t C, float eps);
-int avsr_bn_apply(avsr_stream_t stream, int dtype, const void* x, const void* residual, void* y,
+/* y = act(x*scale + shift (+ residual)); x may be fp32 while y / residual are bf16 */
+int avsr_bn_apply(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, const void* residual, void* y,
                   const float* scale, const float* shift, int64_t rows, int64_t C, int relu);
 
 /* ------------------------------------------------------------------------
@@ -160,7 +161,8 @@ int avsr_bn_apply(avsr_stream_t stream, int dtype, const void* x, const void* re
  * targets: int64 [B, ldt]; target_width = targets.shape[1].
  * out3 = {ctc, ce, number of CE targets kept}.  The workspace (size from
  * avsr_head_loss_workspace_floats) carries lse / alpha / beta to the backward,
- * which writes d(w_ctc*ctc + w_ce*ce)/d(logits) * upstream[0].
+ * which writes d(w_ctc*up_ctc[0]*ctc + w_ce*up_ce[0]*ce)/d(logits) (a NULL
+ * device scalar counts as 1).
  * ---------------------------------------------------------------------- */
 int64_t avsr_head_loss_workspace_floats(int64_t B, int64_t T, int64_t target_width);
 int avsr_head_loss_fwd(avsr_stream_t stream, const float* logits, int64_t ld, int64_t B, int64_t T, int64_t V,
@@ -171,7 +173,7 @@ int avsr_head_loss_bwd(avsr_stream_t stream, int grad_dtype, const float* logits
                        int64_t T, int64_t V, const int64_t* targets, int64_t ldt, int64_t target_width,
                        const int64_t* input_lengths, const int64_t* target_lengths, float label_smoothing,
                        int64_t ignore_index, int64_t blank, const float* ws, float w_ctc, float w_ce,
-                       const float* upstream, void* dlogits, int64_t lddx);
+                       const float* up_ctc, const float* up_ce, void* dlogits, int64_t lddx);
 /* torch.argmax(logits, -1) (train.py:137): first maximum wins. */
 int avsr_argmax_rows(avsr_stream_t stream, const float* x, int64_t ld, int64_t rows, int64_t V, int64_t* out);
 

@@ -3,5 +3,11 @@ behind the reference's ``AVNet`` module surface.  Compute runs in hand-written
 HIP kernels (``csrc/``) reached through a C ABI (``include/avsr_hip.h``);
 PyTorch supplies device memory, streams and ``torch.distributed`` only."""
 from . import _lib, ops  # noqa: F401
+from .av_net import AVNet
+from .gate_cross_attention import GatedCrossAttentionBlock, GatedCrossModalFusion, LayerNorm
+from .moco_visual_frontend import MoCoVisualFrontend
+from .utils import Decoder, PositionalEncoding
+from .whisper_encoder import WhisperConfig, WhisperEncoder, WhisperModel
 
-__all__ = ["_lib", "ops"]
+__all__ = ["AVNet", "GatedCrossAttentionBlock", "GatedCrossModalFusion", "LayerNorm", "MoCoVisualFrontend",
+           "Decoder", "PositionalEncoding", "WhisperConfig", "WhisperEncoder", "WhisperModel", "ops"]

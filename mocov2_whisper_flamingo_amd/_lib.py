@@ -17,7 +17,7 @@ _vp, _i64, _i32, _f32, _u64, _f64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_fl
 
 
 class ConvDesc(_c.Structure):
-    _fields_ = [(n, _i32) for n in ("enabled", "H", "W", "C", "KH", "KW", "stride", "pad", "OH", "OW")]
+    _fields_ = [(n, _i32) for n in ("enabled", "H", "W", "C", "KH", "KW", "stride", "pad_h", "pad_w", "OH", "OW")]
 
 
 class GemmDesc(_c.Structure):
@@ -43,15 +43,15 @@ SIGNATURES = {
     "avsr_attn_bwd": (_i32, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
                              _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64]),
     "avsr_stem3d_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
-    "avsr_maxpool3x3s2": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
+    "avsr_maxpool3x3s2": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
     "avsr_avgpool_mask_fwd": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
     "avsr_bn_finalize": (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32]),
     "avsr_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32]),
-    "avsr_bn_apply": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32]),
+    "avsr_bn_apply": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32]),
     "avsr_head_loss_workspace_floats": (_i64, [_i64, _i64, _i64]),
     "avsr_head_loss_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _i64, _i64, _vp, _vp]),
     "avsr_head_loss_bwd": (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _i64, _i64,
-                                  _vp, _f32, _f32, _vp, _vp, _i64]),
+                                  _vp, _f32, _f32, _vp, _vp, _vp, _i64]),
     "avsr_argmax_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "avsr_cast": (_i32, [_vp, _i32, _i32, _vp, _vp, _i64, _f32]),
     "avsr_transpose": (_i32, [_vp, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _f32]),

@@ -1,0 +1,142 @@
+"""``AVNet`` with the reference's constructor / forward surface and state-dict keys
+(models/av_net.py:14-114), running on the HIP kernels.
+
+Drop-in use: ``AVNet(modal, MoCofile, reqInpLen, modelargs, vocab_size)`` then
+``logits = model((audio, audio_mask, video, video_mask, video_len))``.
+Keyword-only extensions (defaults keep the reference call valid):
+``whisper_config`` (the reference hard-codes "openai/whisper-small" and fetches
+it by name; there is no network here, so the architecture is instantiated from
+a config with random weights, or from ``whisper_state`` tensors), ``dtype`` (the
+compute dtype: ``torch.bfloat16`` or ``torch.float32``) and ``device``.
+
+There is no CPU path: the module's parameters must live on a GPU and the HIP
+library must be built, otherwise the first call raises.
+"""
+import logging
+import zlib
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import ops
+from .gate_cross_attention import GatedCrossModalFusion, LayerNorm
+from .moco_visual_frontend import MoCoVisualFrontend
+from .utils import Decoder, PositionalEncoding
+from .whisper_encoder import WhisperConfig, WhisperModel
+
+logger = logging.getLogger(__name__)
+
+
+class AVNet(nn.Module):
+    def __init__(self, modal, MoCofile, reqInpLen, modelargs, vocab_size, enable_logging=False, *,
+                 whisper_config="small", whisper_state=None, dtype=torch.bfloat16, device=None, seed=0):
+        super().__init__()
+        self.enable_logging = enable_logging
+        self.modal = modal
+        self.reqInpLen = reqInpLen
+        self.compute_dtype = dtype
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("dtype must be torch.bfloat16 or torch.float32")
+
+        cfg = whisper_config if isinstance(whisper_config, WhisperConfig) else WhisperConfig.from_name(whisper_config)
+        self.whisper_model = WhisperModel(cfg)
+        if whisper_state is not None:
+            self.whisper_model.load_state_dict(whisper_state, strict=False)
+        for p in self.whisper_model.encoder.parameters():      # models/av_net.py:25-26
+            p.requires_grad = False
+
+        d_model = modelargs[0]
+        self.audio_proj = nn.Linear(cfg.d_model, d_model)
+        self.audio_ln = LayerNorm(d_model)
+
+        self.visual_model = MoCoVisualFrontend(enable_logging=enable_logging)
+        if MoCofile is not None:                               # models/av_net.py:40-42
+            state = torch.load(MoCofile, map_location="cpu", weights_only=True)
+            self.visual_model.load_state_dict(state, strict=False)
+        for p in self.visual_model.parameters():               # models/av_net.py:45-46
+            p.requires_grad = False
+        self.visual_model.compute_dtype = dtype
+
+        self.video_proj = nn.Linear(2048, d_model)
+        self.video_ln = LayerNorm(d_model)
+        self.fusion_module = GatedCrossModalFusion(d_model=d_model, n_heads=modelargs[1], n_layers=modelargs[2] // 2,
+                                                   dropout=modelargs[5], enable_logging=enable_logging, dtype=dtype)
+        self.fusion_scalar = nn.Parameter(torch.tensor([1.0]))  # present in checkpoints, unused in forward
+        self.pos_enc_audio = PositionalEncoding(d_model, enable_logging=enable_logging)
+        self.pos_enc_video = PositionalEncoding(d_model, enable_logging=enable_logging)
+        self.decoder = Decoder(d_model=d_model, vocab_size=vocab_size, enable_logging=enable_logging)
+
+        self._cache = Fn.WeightCache(dtype)
+        self._seed, self._step = int(seed), 0
+        self.fusion_module.set_runtime(self._cache, self._dropout_seed)
+        if device is not None:
+            self.to(device)
+
+    # ---- runtime helpers --------------------------------------------------
+    def _dropout_seed(self, tag):
+        """A distinct 64-bit stream id per (construction seed, forward call, site)."""
+        mix = self._seed * 0x9E3779B97F4A7C15 + self._step * 0xBF58476D1CE4E5B9 + zlib.crc32(tag.encode())
+        return mix & 0xFFFFFFFFFFFFFFFF
+
+    def make_padding_mask(self, lengths, max_length):
+        """True = padded position (models/av_net.py:111-114)."""
+        return (torch.arange(max_length, device=lengths.device).expand(lengths.size(0), max_length)
+                >= lengths.unsqueeze(1))
+
+    # ---- the shared trunk of forward() and training_step() -----------------
+    def _features(self, inputBatch):
+        audioBatch, audioMask, videoBatch, videoMask, videoLen = inputBatch
+        if not audioBatch.is_cuda:
+            raise ops._lib.AvsrHipError("AVNet inputs must be on the GPU: this package has no CPU path")
+        cdt = self.compute_dtype
+        self._step += 1
+        # AUDIO: [B,3000,80] is already channels-last, the layout the conv kernel wants
+        channels_last = audioBatch.shape[1] == 3000 and audioBatch.shape[2] == 80
+        enc = self.whisper_model.encoder(audioBatch, attention_mask=None, dtype=cdt, channels_last=channels_last)[0]
+        # VIDEO
+        vis = self.visual_model(videoBatch, videoLen)                       # [B,Tv,2048]
+        B, Ta, D = enc.shape
+        Tv = vis.shape[1]
+        min_len = min(Ta, Tv)
+        # audio_proj / audio_ln / positional add are row-wise, so truncating to min_len first
+        # gives the same rows as the reference's project-then-slice (models/av_net.py:83-94)
+        a_in = enc[:, :min_len].reshape(B * min_len, D) if min_len < Ta else enc.reshape(B * Ta, D)
+        a = Fn.linear(a_in, self.audio_proj.weight, self.audio_proj.bias, self._cache.get(self.audio_proj.weight))
+        a = self.audio_ln(a, self.pos_enc_audio.table(min_len)).view(B, min_len, -1)
+        v_in = vis[:, :min_len].reshape(B * min_len, 2048) if min_len < Tv else vis.reshape(B * Tv, 2048)
+        v = Fn.linear(v_in, self.video_proj.weight, self.video_proj.bias, self._cache.get(self.video_proj.weight))
+        v = self.video_ln(v, self.pos_enc_video.table(min_len)).view(B, min_len, -1)
+        videoLen.clamp_(max=min_len)                                        # in place, as the reference does
+        fused = self.fusion_module(a, v, audio_mask=audioMask[:, :min_len] if audioMask is not None else None,
+                                   video_mask=self.make_padding_mask(videoLen, min_len))
+        d = a.shape[-1]
+        out = Fn.Add3Fn.apply(fused.reshape(B * min_len, d), a.reshape(B * min_len, d), v.reshape(B * min_len, d))
+        return out, B, min_len
+
+    def forward(self, inputBatch):
+        """inputBatch = (audio [B,3000,80] or [B,80,3000], audio_mask, video [B,T,3,H,W],
+        video_mask, video_len int64 [B]) -> fp32 logits [B, min(1500,T), vocab]."""
+        out, B, T = self._features(inputBatch)
+        lin = self.decoder.linear
+        wc, wct = self._cache.get(lin.weight)
+        logits = Fn.LinearFn.apply(out, lin.weight, lin.bias, wc, wct, torch.float32, wct.shape[1])
+        return logits.view(B, T, -1)
+
+    def training_step(self, batch, label_smoothing=0.1):
+        """Counterpart of ``AVSRModule.training_step`` (train.py:143-170): forward,
+        CTC + label-smoothed CE with the head, log-softmax and both losses fused.
+        Returns (loss, ctc, ce, logits)."""
+        inp = (batch["audio"], batch["audio_mask"], batch["video"], batch["video_mask"], batch["video_lengths"])
+        out, B, T = self._features(inp)
+        lin = self.decoder.linear
+        wc, wct = self._cache.get(lin.weight)
+        ctc, ce, logits = Fn.HeadLossFn.apply(out, lin.weight, lin.bias, wc, wct, batch["target_ids"],
+                                              batch["audio_lengths"], batch["target_lengths"].reshape(-1).contiguous(),
+                                              B, T, label_smoothing)
+        return ctc + ce, ctc, ce, logits
+
+    @torch.no_grad()
+    def decode_ids(self, logits):
+        """``torch.argmax(logits, -1)`` of ``_decode_predictions`` (train.py:137)."""
+        return ops.argmax_rows(logits)

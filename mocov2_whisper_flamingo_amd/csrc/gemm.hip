@@ -16,7 +16,7 @@ struct GemmP {
     long lda, ldb, ldc, sA, sB, sC;
     float alpha; const float* scale; const float* bias; int act;
     const void* res; long ldr; int res_period; const float* gate; float* csum; float* csq;
-    int H, W, Cc, KH, KW, stride, pad, OH, OW;
+    int H, W, Cc, KH, KW, stride, pad_h, pad_w, OH, OW;
     int tiles_m, tiles_n, vec_ok;
 };
 
@@ -49,8 +49,8 @@ __device__ __forceinline__ ConvRow conv_row(const GemmP& p, int m) {
     const int img = mm / ohw, rem = mm - img * ohw;
     const int oh = rem / p.OW, ow = rem - oh * p.OW;
     r.base = img * p.H * p.W;
-    r.ih0 = oh * p.stride - p.pad;
-    r.iw0 = ow * p.stride - p.pad;
+    r.ih0 = oh * p.stride - p.pad_h;
+    r.iw0 = ow * p.stride - p.pad_w;
     return r;
 }
 // Column kk of the implicit matrix = filter tap (kh,kw) and channel cc.
@@ -365,8 +365,8 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         const auto& c = g->conv;
         if (c.C % chunk || c.H <= 0 || c.W <= 0 || c.KH <= 0 || c.KW <= 0 || c.stride <= 0) return AVSR_EINVAL;
         if ((int64_t)c.KH * c.KW * c.C != g->K) return AVSR_EINVAL;
-        if (c.OH != (c.H + 2 * c.pad - c.KH) / c.stride + 1) return AVSR_EINVAL;
-        if (c.OW != (c.W + 2 * c.pad - c.KW) / c.stride + 1) return AVSR_EINVAL;
+        if (c.OH != (c.H + 2 * c.pad_h - c.KH) / c.stride + 1) return AVSR_EINVAL;
+        if (c.OW != (c.W + 2 * c.pad_w - c.KW) / c.stride + 1) return AVSR_EINVAL;
         if (g->M % ((int64_t)c.OH * c.OW)) return AVSR_EINVAL;
     } else if (g->lda % chunk) return AVSR_EUNSUPPORTED;
 
@@ -378,7 +378,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     p.alpha = g->alpha; p.scale = g->scale; p.bias = g->bias; p.act = g->act;
     p.res = g->residual; p.ldr = g->ldr; p.res_period = (int)g->res_period; p.gate = g->gate; p.csum = g->col_sum; p.csq = g->col_sumsq;
     p.H = g->conv.H; p.W = g->conv.W; p.Cc = g->conv.C; p.KH = g->conv.KH; p.KW = g->conv.KW;
-    p.stride = g->conv.stride; p.pad = g->conv.pad; p.OH = g->conv.OH; p.OW = g->conv.OW;
+    p.stride = g->conv.stride; p.pad_h = g->conv.pad_h; p.pad_w = g->conv.pad_w; p.OH = g->conv.OH; p.OW = g->conv.OW;
     const size_t osz = g->out_dtype == AVSR_BF16 ? 2 : 4;
     const size_t vbytes = 4 * osz;
     p.vec_ok = (g->ldc % 4 == 0) && aligned_to(g->C, vbytes) && ((g->strideC * osz) % vbytes == 0) &&

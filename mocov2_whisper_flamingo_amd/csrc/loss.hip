@@ -130,17 +130,18 @@ __global__ __launch_bounds__(256) void head_grad_dense_kernel(const float* __res
                                                               const int64_t* __restrict__ tg_len, const float* __restrict__ nll,
                                                               const float* __restrict__ ce_out, int B, int T, int t_ce, float eps,
                                                               int ignore_index, float w_ctc, float w_ce,
-                                                              const float* __restrict__ upstream, TG* __restrict__ dx, long lddx) {
+                                                              const float* __restrict__ up_ctc, const float* __restrict__ up_ce,
+                                                              TG* __restrict__ dx, long lddx) {
     const long row = blockIdx.x;
     const int b = (int)(row / T), t = (int)(row - (long)b * T);
-    const float up = upstream ? upstream[0] : 1.f;
+    const float upc = up_ctc ? up_ctc[0] : 1.f, upe = up_ce ? up_ce[0] : 1.f;
     float gctc = 0.f;
     if (t < in_len[b] && nll[b] != INFINITY && nll[b] == nll[b])
-        gctc = up * w_ctc / ((float)B * (float)max((long)tg_len[b], 1L));
+        gctc = upc * w_ctc / ((float)B * (float)max((long)tg_len[b], 1L));
     float gce = 0.f; long tg = -1;
     if (t < t_ce) {
         tg = targets[(long)b * ldt + t];
-        if (tg != ignore_index && ce_out[1] > 0.f) gce = up * w_ce / ce_out[1]; else tg = -1;
+        if (tg != ignore_index && ce_out[1] > 0.f) gce = upe * w_ce / ce_out[1]; else tg = -1;
     }
     const float* xr = x + row * ld;
     TG* dr = dx + row * lddx;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(64) void ctc_grad_sparse_kernel(const float* __rest
                                                             const int64_t* __restrict__ in_len, const int64_t* __restrict__ tg_len,
                                                             const float* __restrict__ alpha, const float* __restrict__ beta,
                                                             const float* __restrict__ nll, int B, int T, int Smax, int blank,
-                                                            float w_ctc, const float* __restrict__ upstream, TG* __restrict__ dx,
+                                                            float w_ctc, const float* __restrict__ up_ctc, TG* __restrict__ dx,
                                                             long lddx) {
     const long row = (long)blockIdx.x * 64 + threadIdx.x;
     if (row >= (long)B * T) return;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(64) void ctc_grad_sparse_kernel(const float* __rest
     const float nl = nll[b];
     if (nl == INFINITY || nl != nl) return;
     const int L = (int)tg_len[b], S = 2 * L + 1;
-    const float up = upstream ? upstream[0] : 1.f;
+    const float up = up_ctc ? up_ctc[0] : 1.f;
     const float g = up * w_ctc / ((float)B * (float)max((long)L, 1L));
     const int64_t* tg = targets + (long)b * ldt;
     const float* al = alpha + ((long)b * T + t) * Smax;
@@ -246,7 +247,7 @@ extern "C" int avsr_head_loss_bwd(avsr_stream_t stream, int grad_dtype, const fl
                                   int64_t T, int64_t V, const int64_t* targets, int64_t ldt, int64_t max_target_len,
                                   const int64_t* input_lengths, const int64_t* target_lengths, float label_smoothing,
                                   int64_t ignore_index, int64_t blank, const float* ws, float w_ctc, float w_ce,
-                                  const float* upstream, void* dlogits, int64_t lddx) {
+                                  const float* up_ctc, const float* up_ce, void* dlogits, int64_t lddx) {
     if (!logits || !targets || !input_lengths || !target_lengths || !ws || !dlogits) return AVSR_EINVAL;
     if (B <= 0 || T <= 0 || V <= 0 || max_target_len <= 0 || max_target_len > ldt) return AVSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -257,10 +258,10 @@ extern "C" int avsr_head_loss_bwd(avsr_stream_t stream, int grad_dtype, const fl
 #define RUN(TG)                                                                                                          \
     hipLaunchKernelGGL(head_grad_dense_kernel<TG>, dim3((unsigned)rows), dim3(256), 0, s, logits, (long)ld, (int)V, lse, \
                        targets, (long)ldt, input_lengths, target_lengths, nll, ce, (int)B, (int)T, t_ce, label_smoothing,\
-                       (int)ignore_index, w_ctc, w_ce, upstream, (TG*)dlogits, (long)lddx);                              \
+                       (int)ignore_index, w_ctc, w_ce, up_ctc, up_ce, (TG*)dlogits, (long)lddx);                              \
     hipLaunchKernelGGL(ctc_grad_sparse_kernel<TG>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, logits, (long)ld, \
                        lse, targets, (long)ldt, input_lengths, target_lengths, alpha, beta, nll, (int)B, (int)T,         \
-                       (int)Smax, (int)blank, w_ctc, upstream, (TG*)dlogits, (long)lddx)
+                       (int)Smax, (int)blank, w_ctc, up_ctc, (TG*)dlogits, (long)lddx)
     if (grad_dtype == AVSR_F32) { RUN(float); }
     else if (grad_dtype == AVSR_BF16) { RUN(bf16_t); }
     else return AVSR_EINVAL;

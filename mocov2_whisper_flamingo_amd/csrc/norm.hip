@@ -218,15 +218,15 @@ __global__ void bn_fold_kernel(const float* __restrict__ weight, const float* __
 
 // y = act(x*scale[c] + shift[c] (+ residual)) over an NHWC tensor [rows, C];
 // 8 (bf16) or 4 (f32) channels per thread, grid-stride.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const TI* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        long n4, int C, int relu) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const int c = (int)((i * 4) % C);
         float v[4], sc[4], sh[4];
-        load4<T>(x + i * 4, v);
+        load4<TI>(x + i * 4, v);
         load4<float>(scale + c, sc);
         load4<float>(shift + c, sh);
 #pragma unroll
@@ -258,20 +258,20 @@ extern "C" int avsr_bn_fold(avsr_stream_t stream, const float* weight, const flo
     return avsr_launch_status();
 }
 
-extern "C" int avsr_bn_apply(avsr_stream_t stream, int dtype, const void* x, const void* residual, void* y,
-                             const float* scale, const float* shift, int64_t rows, int64_t C, int relu) {
+extern "C" int avsr_bn_apply(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, const void* residual,
+                             void* y, const float* scale, const float* shift, int64_t rows, int64_t C, int relu) {
     if (!x || !y || !scale || !shift || rows <= 0 || C <= 0) return AVSR_EINVAL;
     if (C % 4) return AVSR_EUNSUPPORTED;
     const long n4 = rows * C / 4;
     long nb = (n4 + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == AVSR_F32)
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)x, (const float*)residual,
-                           (float*)y, scale, shift, n4, (int)C, relu);
-    else if (dtype == AVSR_BF16)
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)x,
-                           (const bf16_t*)residual, (bf16_t*)y, scale, shift, n4, (int)C, relu);
+#define L(TI, TO) hipLaunchKernelGGL((bn_apply_kernel<TI, TO>), dim3((unsigned)nb), dim3(256), 0, s, (const TI*)x, \
+                                     (const TO*)residual, (TO*)y, scale, shift, n4, (int)C, relu)
+    if (in_dtype == AVSR_F32 && out_dtype == AVSR_F32) L(float, float);
+    else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_BF16) L(bf16_t, bf16_t);
+    else if (in_dtype == AVSR_F32 && out_dtype == AVSR_BF16) L(float, bf16_t);
     else return AVSR_EINVAL;
+#undef L
     return avsr_launch_status();
 }

@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void stem3d_kernel(const float* __restrict__ v
 
 // MaxPool (1,3,3)/(1,2,2)/(0,1,1) over NHWC; optional affine + ReLU applied to
 // every element before the max (training-mode BN, whose scale may be negative).
-template <typename T>
-__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y,
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ x, TO* __restrict__ y,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            int N, int H, int W, int C, int OH, int OW) {
     const int c4n = C >> 2;
@@ -122,9 +122,9 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
                     m[e] = fmaxf(m[e], v);
                 }
             }
-        T* q = y + (((long)n * OH + oh) * OW + ow) * C + c4 * 4;
+        TO* q = y + (((long)n * OH + oh) * OW + ow) * C + c4 * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) q[e] = from_f32<T>(m[e]);
+        for (int e = 0; e < 4; ++e) q[e] = from_f32<TO>(m[e]);
     }
 }
 
@@ -165,8 +165,8 @@ extern "C" int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float*
     return avsr_launch_status();
 }
 
-extern "C" int avsr_maxpool3x3s2(avsr_stream_t stream, int dtype, const void* x, void* y, const float* scale,
-                                 const float* shift, int64_t N, int64_t H, int64_t W, int64_t C) {
+extern "C" int avsr_maxpool3x3s2(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y,
+                                 const float* scale, const float* shift, int64_t N, int64_t H, int64_t W, int64_t C) {
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return AVSR_EINVAL;
     if (C % 4) return AVSR_EUNSUPPORTED;
     if ((scale == nullptr) != (shift == nullptr)) return AVSR_EINVAL;
@@ -175,13 +175,13 @@ extern "C" int avsr_maxpool3x3s2(avsr_stream_t stream, int dtype, const void* x,
     long nb = (total + 255) / 256;
     if (nb > 8192) nb = 8192;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == AVSR_F32)
-        hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)x, (float*)y, scale,
-                           shift, (int)N, (int)H, (int)W, (int)C, OH, OW);
-    else if (dtype == AVSR_BF16)
-        hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,
-                           scale, shift, (int)N, (int)H, (int)W, (int)C, OH, OW);
+#define L(TI, TO) hipLaunchKernelGGL((maxpool3x3s2_kernel<TI, TO>), dim3((unsigned)nb), dim3(256), 0, s, (const TI*)x, (TO*)y, \
+                                     scale, shift, (int)N, (int)H, (int)W, (int)C, OH, OW)
+    if (in_dtype == AVSR_F32 && out_dtype == AVSR_F32) L(float, float);
+    else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_BF16) L(bf16_t, bf16_t);
+    else if (in_dtype == AVSR_F32 && out_dtype == AVSR_BF16) L(float, bf16_t);
     else return AVSR_EINVAL;
+#undef L
     return avsr_launch_status();
 }
 

@@ -1,0 +1,195 @@
+"""``torch.autograd.Function`` wrappers for the trainable tail of AVNet
+(projections, LayerNorms, the gated cross-attention fusion, the vocabulary head
+and its losses).  Forward and backward both run in the HIP kernels behind
+``ops``; autograd only chains them and accumulates parameter gradients.
+
+All activations are 2-D ``[rows, features]`` (or ``[B, T, features]`` for
+attention) tensors of the compute dtype; parameter gradients are fp32.
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+class WeightCache:
+    """Compute-dtype copies of trainable parameters, refreshed when the
+    parameter's version counter moves (an optimizer step or a state-dict load).
+    ``get(p)`` -> (W as [N,K] in cdt, W^T as [K, N rounded up to 8] in cdt)."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self._store = {}
+
+    def get(self, p):
+        key = id(p)
+        hit = self._store.get(key)
+        ver = (p._version, p.data_ptr())
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2]
+        with torch.no_grad():
+            w = p.detach()
+            wc = w if self.dtype == torch.float32 else ops.cast(w, self.dtype)
+            wct = ops.transpose2d(w, dtype=self.dtype, pad_to=8)
+        self._store[key] = (ver, wc, wct)
+        return wc, wct
+
+    def clear(self):
+        self._store.clear()
+
+
+class LinearFn(Function):
+    """y = x W^T + b  (every nn.Linear of the tail).  ``w``/``b`` are (views of)
+    the fp32 parameters and only route gradients; ``wc``/``wct`` are the cached
+    compute-dtype copies the kernels read."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, wc, wct, out_dtype, ld_out):
+        N = wc.shape[0]
+        if ld_out is None:
+            y = ops.gemm_nt(x, wc, bias=b, out_dtype=out_dtype)
+        else:   # padded leading dimension: the result is a [M, N] view of a [M, ld_out] buffer
+            buf = torch.empty((x.shape[0], ld_out), dtype=out_dtype or x.dtype, device=x.device)
+            y = ops.gemm_nt(x, wc, bias=b, out=buf[:, :N])
+        ctx.save_for_backward(x, wct)
+        ctx.has_bias = b is not None
+        ctx.N = N
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wct = ctx.saved_tensors
+        M, N = x.shape[0], ctx.N
+        cdt = x.dtype
+        Np = wct.shape[1]
+        if dy.dtype != cdt or dy.stride(-1) != 1 or (Np != N and dy.stride(0) < Np):
+            pad = torch.zeros((M, Np), dtype=cdt, device=x.device) if Np != N else torch.empty((M, N), dtype=cdt,
+                                                                                               device=x.device)
+            pad[:, :N].copy_(dy)
+            dy = pad[:, :N]
+        dyk = dy if Np == N else torch.as_strided(dy, (M, Np), (dy.stride(0), 1))   # padding columns are zero
+        dx = ops.gemm_nt(dyk, wct) if ctx.needs_input_grad[0] else None
+        dyt = ops.transpose2d(dy, pad_to=8)                     # [N, Mp]
+        xt = ops.transpose2d(x, pad_to=8)                       # [K, Mp]
+        dw = ops.gemm_nt(dyt, xt, out_dtype=torch.float32)      # [N, K]
+        db = ops.colsum(dy) if ctx.has_bias else None
+        return dx, dw, db, None, None, None, None
+
+
+class LayerNormFn(Function):
+    """LayerNorm in fp32 with an optional additive table (positional encoding)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, add):
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, add=add, save_stats=True)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(gamma)
+        dy = dy if dy.stride(-1) == 1 else dy.contiguous()
+        dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db)
+        return dx, dg, db, None
+
+
+class GeluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_bwd(x, dy.contiguous())
+
+
+class GatedResidualFn(Function):
+    """out = x + tanh(gate) * dropout(y)."""
+
+    @staticmethod
+    def forward(ctx, x, y, gate, p_drop, seed):
+        ctx.save_for_backward(y, gate)
+        ctx.p_drop, ctx.seed = p_drop, seed
+        return ops.gated_residual_fwd(x, y, gate, p_drop, seed)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gate = ctx.saved_tensors
+        dout = dout.contiguous()
+        dgate = torch.zeros_like(gate)
+        dy = ops.gated_residual_bwd(dout, y, gate, dgate, ctx.p_drop, ctx.seed)
+        return dout, dy, dgate, None, None
+
+
+class AttnFn(Function):
+    """softmax(q k^T * scale + key mask) v with attention dropout, per head."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_mask, H, scale, p_drop, seed):
+        o, lse = ops.attn_fwd(q, k, v, H, key_mask=key_mask, scale=scale, save_lse=True, p_drop=p_drop, seed=seed)
+        ctx.save_for_backward(q, k, v, o, lse, key_mask)
+        ctx.cfg = (H, scale, p_drop, seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, key_mask = ctx.saved_tensors
+        H, scale, p_drop, seed = ctx.cfg
+        dq, dk, dv = ops.attn_bwd(q, k, v, o, do, lse, H, key_mask=key_mask, scale=scale, p_drop=p_drop, seed=seed)
+        return dq, dk, dv, None, None, None, None, None
+
+
+class Add3Fn(Function):
+    @staticmethod
+    def forward(ctx, a, b, c):
+        return ops.add3(a, b, c)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d, d
+
+
+class HeadLossFn(Function):
+    """Vocabulary head + CTC + label-smoothed CE in one node (models/utils.py:40 and
+    train.py:95-128).  Returns (ctc, ce, logits); the logits output is a
+    non-differentiable view - gradients reach the head only through the two
+    losses, and d(loss)/d(logits) is written once, in the compute dtype, straight
+    into the buffer the two backward GEMMs read."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, wc, wct, targets, input_lengths, target_lengths, B, T, label_smoothing):
+        V = wc.shape[0]
+        ld = wct.shape[1]
+        buf = torch.empty((B * T, ld), dtype=torch.float32, device=x.device)
+        ops.gemm_nt(x, wc, bias=b, out=buf[:, :V])
+        logits = buf.view(B, T, ld)[:, :, :V]
+        out3, ws = ops.head_loss_fwd(logits, targets, input_lengths, target_lengths, label_smoothing)
+        ctx.save_for_backward(x, wct, buf, ws, targets, input_lengths, target_lengths)
+        ctx.cfg = (B, T, V, ld, label_smoothing)
+        ctx.mark_non_differentiable(logits)
+        return out3[0], out3[1], logits
+
+    @staticmethod
+    def backward(ctx, g_ctc, g_ce, _g_logits):
+        x, wct, buf, ws, targets, input_lengths, target_lengths = ctx.saved_tensors
+        B, T, V, ld, ls = ctx.cfg
+        logits = buf.view(B, T, ld)[:, :, :V]
+        gc = g_ctc.reshape(1).float().contiguous() if g_ctc is not None else torch.zeros(1, device=x.device)
+        ge = g_ce.reshape(1).float().contiguous() if g_ce is not None else torch.zeros(1, device=x.device)
+        dl = ops.head_loss_bwd(logits, targets, input_lengths, target_lengths, ws, x.dtype, label_smoothing=ls,
+                               up_ctc=gc, up_ce=ge, ld_out=ld)                       # [B*T, ld], pad columns zero
+        dx = ops.gemm_nt(dl, wct)
+        dlt = ops.transpose2d(dl[:, :V], pad_to=8)
+        xt = ops.transpose2d(x, pad_to=8)
+        dw = ops.gemm_nt(dlt, xt, out_dtype=torch.float32)
+        db = ops.colsum(dl[:, :V])
+        return dx, dw, db, None, None, None, None, None, None, None, None
+
+
+def linear(x, w, b, cache_entry, out_dtype=None, ld_out=None):
+    wc, wct = cache_entry
+    return LinearFn.apply(x, w, b, wc, wct, out_dtype, ld_out)

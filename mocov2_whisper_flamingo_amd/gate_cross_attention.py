@@ -1,0 +1,109 @@
+"""Flamingo-style tanh-gated cross-attention fusion on the HIP kernels, with the
+reference's classes, constructor signatures and state-dict keys
+(models/gate_cross_attention.py:8-73).  These blocks are trainable: forward and
+backward run through the autograd wrappers in ``functional``.
+
+Everything operates on ``[B, T, d]`` GPU tensors of the compute dtype.  A query
+row whose keys are all masked attends to nothing (its attention output is the
+out-projection bias) instead of producing NaN.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+
+
+class LayerNorm(nn.LayerNorm):
+    """LayerNorm computed in fp32 and cast back to the input dtype
+    (models/gate_cross_attention.py:8-10)."""
+
+    def forward(self, x, add=None):
+        shp = x.shape
+        y = Fn.LayerNormFn.apply(x.reshape(-1, shp[-1]), self.weight, self.bias, add)
+        return y.view(shp)
+
+
+class GatedCrossAttentionBlock(nn.Module):
+    def __init__(self, d_model, n_heads, dropout=0.1, enable_logging=False):
+        super().__init__()
+        self.enable_logging = enable_logging
+        # parameter container with nn.MultiheadAttention's names: in_proj_weight, in_proj_bias, out_proj.*
+        self.attn = nn.MultiheadAttention(embed_dim=d_model, num_heads=n_heads, dropout=dropout, batch_first=True)
+        self.attn_ln = LayerNorm(d_model)
+        self.ff_ln = LayerNorm(d_model)
+        self.attn_gate = nn.Parameter(torch.tensor([0.]))
+        self.ff_gate = nn.Parameter(torch.tensor([0.]))
+        n_mlp = d_model * 4
+        self.ff = nn.Sequential(nn.Linear(d_model, n_mlp), nn.GELU(), nn.Linear(n_mlp, d_model), nn.Dropout(dropout))
+        self.d_model, self.n_heads, self.p_drop = d_model, n_heads, dropout
+        self._cache = None          # WeightCache, set by the owner
+        self._seed_fn = lambda tag: 0
+
+    def forward(self, x, xa=None, mask=None):
+        """x [B,T,d]; xa [B,Tk,d] or None (skips attention); mask bool/uint8 [B,Tk], True = padded key."""
+        if xa is not None and xa.dim() == 4 and xa.size(1) == 1:
+            xa = xa.squeeze(1)
+        if mask is not None and mask.dim() == 3 and mask.size(1) == 1:
+            mask = mask.squeeze(1)
+        B, T, d = x.shape
+        H = self.n_heads
+        if d // H != 64:
+            raise ValueError("attention kernels are built for head_dim 64")
+        p = self.p_drop if self.training else 0.0
+        cache = self._cache
+        x2 = x.reshape(B * T, d)
+        if xa is not None:
+            Tk = xa.shape[1]
+            km = None if mask is None else mask.to(torch.uint8).contiguous()
+            wc, wct = cache.get(self.attn.in_proj_weight)
+            w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+            h = self.attn_ln(x2)
+            q = Fn.linear(h, w[:d], b[:d], (wc[:d], wct[:, :d]))
+            kv = Fn.linear(xa.reshape(B * Tk, d), w[d:], b[d:], (wc[d:], wct[:, d:]))
+            kv = kv.view(B, Tk, 2 * d)
+            a = Fn.AttnFn.apply(q.view(B, T, d), kv[:, :, :d], kv[:, :, d:], km, H, 64 ** -0.5, p,
+                                self._seed_fn("attn"))
+            ao = Fn.linear(a.view(B * T, d), self.attn.out_proj.weight, self.attn.out_proj.bias,
+                           cache.get(self.attn.out_proj.weight))
+            x2 = Fn.GatedResidualFn.apply(x2, ao, self.attn_gate, 0.0, 0)
+        h = self.ff_ln(x2)
+        f = Fn.linear(h, self.ff[0].weight, self.ff[0].bias, cache.get(self.ff[0].weight))
+        f = Fn.GeluFn.apply(f)
+        f = Fn.linear(f, self.ff[2].weight, self.ff[2].bias, cache.get(self.ff[2].weight))
+        x2 = Fn.GatedResidualFn.apply(x2, f, self.ff_gate, p, self._seed_fn("ff"))
+        return x2.view(B, T, d)
+
+
+class GatedCrossModalFusion(nn.Module):
+    def __init__(self, d_model, n_heads, n_layers, dropout=0.1, enable_logging=False, dtype=torch.bfloat16):
+        super().__init__()
+        self.enable_logging = enable_logging
+        self.audio_proj = nn.Linear(d_model, d_model)
+        self.video_proj = nn.Linear(d_model, d_model)
+        self.layers = nn.ModuleList([GatedCrossAttentionBlock(d_model, n_heads, dropout, enable_logging=enable_logging)
+                                     for _ in range(n_layers)])
+        self.ln_post = LayerNorm(d_model)
+        self.set_runtime(Fn.WeightCache(dtype), lambda tag: 0)
+
+    def set_runtime(self, cache, seed_fn):
+        """Share one weight cache / dropout-seed source with the owning AVNet."""
+        self._cache = cache
+        for i, layer in enumerate(self.layers):
+            layer._cache = cache
+            layer._seed_fn = (lambda tag, i=i: seed_fn(f"fusion.{i}.{tag}"))
+
+    def forward(self, audio_features, video_features, audio_mask=None, video_mask=None):
+        """``audio_mask`` is accepted and unused, as in the reference
+        (models/gate_cross_attention.py:60-70)."""
+        B, T, d = audio_features.shape
+        Tk = video_features.shape[1]
+        cdt = self._cache.dtype
+        a = audio_features if audio_features.dtype == cdt else audio_features.to(cdt)
+        v = video_features if video_features.dtype == cdt else video_features.to(cdt)
+        x = Fn.linear(a.reshape(B * T, d), self.audio_proj.weight, self.audio_proj.bias,
+                      self._cache.get(self.audio_proj.weight)).view(B, T, d)
+        xa = Fn.linear(v.reshape(B * Tk, d), self.video_proj.weight, self.video_proj.bias,
+                       self._cache.get(self.video_proj.weight)).view(B, Tk, d)
+        for layer in self.layers:
+            x = layer(x, xa, video_mask)
+        return self.ln_post(x)

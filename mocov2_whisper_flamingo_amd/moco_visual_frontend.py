@@ -1,0 +1,157 @@
+"""MoCo v2 visual frontend (3D stem + ResNet-50 trunk) on the HIP kernels, with
+the reference's parameter names (``frontend3D.{0,1}.*``, ``MoCoModel.layer{1-4}.
+{j}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample.{0,1}}.*``;
+models/moco_visual_frontend.py:14-26, torchvision ``resnet50`` with
+conv1/bn1/relu/maxpool/fc = Identity).
+
+Frozen in the reference (models/av_net.py:45-46): forward only.  Activations are
+NHWC; every convolution of the trunk is an implicit GEMM.  BatchNorm follows
+``self.training`` like the reference does: eval = running statistics folded
+into the GEMM epilogue; train = batch statistics accumulated in the epilogue,
+one finalize + one apply kernel per BN, running statistics updated in place
+(the pre-normalisation tensor stays fp32 so the batch statistics and the
+normalised values see the same numbers).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+BLOCKS = (3, 4, 6, 3)
+WIDTHS = (64, 128, 256, 512)
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, inplanes, width, stride):
+        super().__init__()
+        out = width * 4
+        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, out, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(out)
+        self.stride = stride
+        if stride != 1 or inplanes != out:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, out, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(out))
+        else:
+            self.downsample = None
+
+
+class _ResNet50Trunk(nn.Module):
+    def __init__(self):
+        super().__init__()
+        inplanes = 64
+        for li, (n, w) in enumerate(zip(BLOCKS, WIDTHS)):
+            blocks = []
+            for j in range(n):
+                blocks.append(_Bottleneck(inplanes, w, 2 if (li > 0 and j == 0) else 1))
+                inplanes = w * 4
+            setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
+        # torchvision's resnet50 initialisation
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def blocks(self):
+        for li in range(4):
+            yield from getattr(self, f"layer{li + 1}")
+
+
+class MoCoVisualFrontend(nn.Module):
+    def __init__(self, d_model=512, num_classes=500, frame_length=96, vid_feature_dim=512, enable_logging=False):
+        super().__init__()
+        self.enable_logging = enable_logging
+        self.frontend3D = nn.Sequential(
+            nn.Conv3d(3, 64, kernel_size=(5, 3, 3), stride=(1, 2, 2), padding=(2, 3, 3), bias=False),
+            nn.BatchNorm3d(64),
+            nn.ReLU(True),
+            nn.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1)),
+        )
+        self.MoCoModel = _ResNet50Trunk()
+        self.compute_dtype = torch.bfloat16
+        self._packed = None
+
+    # ---- weight packing -------------------------------------------------
+    def _pack(self, dtype):
+        key = (dtype, self.training, sum(p._version for p in self.parameters()),
+               0 if self.training else sum(b._version for b in self.buffers()), next(self.parameters()).data_ptr())
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+
+        def cw(conv):   # [Co, Ci, kh, kw] -> [Co, kh*kw*Ci] in the compute dtype
+            w = conv.weight.detach()
+            return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
+
+        pk = {"stem_w": self.frontend3D[0].weight.detach().float().contiguous(), "blocks": [], "fold": {}}
+        if not self.training:      # eval: fold every BN's running statistics once per weight version
+            for m in self.modules():
+                if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+                    pk["fold"][id(m)] = ops.bn_fold(m.weight.detach(), m.bias.detach(), m.running_mean, m.running_var, m.eps)
+        for blk in self.MoCoModel.blocks():
+            e = {"w1": cw(blk.conv1), "w2": cw(blk.conv2), "w3": cw(blk.conv3), "stride": blk.stride}
+            if blk.downsample is not None:
+                e["wd"] = cw(blk.downsample[0])
+            pk["blocks"].append(e)
+        self._packed = (key, pk)
+        return pk
+
+    def _fold(self, bn):
+        return self._packed[1]["fold"][id(bn)]
+
+    # ---- one conv + BN (+ReLU / + residual) ------------------------------------
+    def _conv_bn(self, x, w, k, stride, pad, bn, relu, residual=None):
+        if not self.training:
+            sc, sh = self._fold(bn)
+            if residual is not None:
+                act = ops.ACT_RELU_AFTER_RESIDUAL
+                res2d = residual.view(-1, residual.shape[-1])
+            else:
+                act, res2d = (ops.ACT_RELU if relu else ops.ACT_NONE), None
+            return ops.conv_nhwc(x, w, k, k, stride, pad, scale=sc, bias=sh, act=act, residual=res2d)
+        C = w.shape[0]
+        stats = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+        raw = ops.conv_nhwc(x, w, k, k, stride, pad, col_stats=(stats[0], stats[1]), out_dtype=torch.float32)
+        sc = torch.empty(C, dtype=torch.float32, device=x.device)
+        sh = torch.empty(C, dtype=torch.float32, device=x.device)
+        ops.bn_finalize(stats[0], stats[1], raw.numel() // C, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                        bn.running_var, sc, sh, bn.eps, bn.momentum)
+        return ops.bn_apply(raw, sc, sh, residual=residual, relu=relu, out_dtype=x.dtype)
+
+    @torch.no_grad()
+    def forward(self, x, x_len):
+        """x: [B,T,3,H,W] (or [B,1,T,3,H,W]) fp32, x_len: int64 [B] -> [B,T,2048]
+        in the compute dtype, rows t >= x_len[b] zero."""
+        if x.dim() == 6 and x.shape[1] == 1:
+            x = x.squeeze(1)
+        dtype = self.compute_dtype
+        pk = self._pack(dtype)
+        B, T = x.shape[0], x.shape[1]
+        video = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+        bn0 = self.frontend3D[1]
+        if not self.training:
+            sc, sh = self._fold(bn0)
+            y = ops.stem3d_fwd(video, pk["stem_w"], dtype, scale=sc, shift=sh)
+            y = ops.maxpool3x3s2(y)
+        else:
+            stats = torch.zeros((2, 64), dtype=torch.float32, device=x.device)
+            raw = ops.stem3d_fwd(video, pk["stem_w"], torch.float32, col_stats=(stats[0], stats[1]))
+            sc = torch.empty(64, dtype=torch.float32, device=x.device)
+            sh = torch.empty(64, dtype=torch.float32, device=x.device)
+            ops.bn_finalize(stats[0], stats[1], raw.numel() // 64, bn0.weight.detach(), bn0.bias.detach(),
+                            bn0.running_mean, bn0.running_var, sc, sh, bn0.eps, bn0.momentum)
+            y = ops.maxpool3x3s2(raw, scale=sc, shift=sh, out_dtype=dtype)
+        for blk, e in zip(self.MoCoModel.blocks(), pk["blocks"]):
+            idt = y
+            if "wd" in e:
+                idt = self._conv_bn(y, e["wd"], 1, e["stride"], 0, blk.downsample[1], relu=False)
+            h = self._conv_bn(y, e["w1"], 1, 1, 0, blk.bn1, relu=True)
+            h = self._conv_bn(h, e["w2"], 3, e["stride"], 1, blk.bn2, relu=True)
+            y = self._conv_bn(h, e["w3"], 1, 1, 0, blk.bn3, relu=True, residual=idt)
+        if self.training:   # one fused increment for all 54 counters
+            torch._foreach_add_([m.num_batches_tracked for m in self.modules()
+                                 if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d))], 1)
+        return ops.avgpool_mask(y, x_len, B, T, dtype)

@@ -36,18 +36,19 @@ def _need_cuda(*ts):
 def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NONE, residual=None,
             res_period=0, gate=None, alpha=1.0, col_stats=None, conv=None, M=None):
     """out[m,n] = epi(sum_k a[m,k] b[n,k]).  a: [M,K] or [batch,M,K]; b: [N,K] or [batch,N,K].
-    conv = (H, W, C, KH, KW, stride, pad, OH, OW): a is an NHWC image batch and M = n_img*OH*OW."""
+    conv = (H, W, C, KH, KW, stride, pad_h, pad_w, OH, OW): a is an NHWC image batch, M = n_img*OH*OW."""
     lib = _lib.load()
     _need_cuda(a, b, out, bias, scale, residual, gate)
     d = GemmDesc()
     batched = b.dim() == 3
     N, K = b.shape[-2], b.shape[-1]
     if conv is not None:
-        H, W, C, KH, KW, stride, pad, OH, OW = conv
+        H, W, C, KH, KW, stride, pad_h, pad_w, OH, OW = conv
         if not a.is_contiguous():
             raise ValueError("conv input must be contiguous NHWC")
         d.conv.enabled, d.conv.H, d.conv.W, d.conv.C = 1, H, W, C
-        d.conv.KH, d.conv.KW, d.conv.stride, d.conv.pad, d.conv.OH, d.conv.OW = KH, KW, stride, pad, OH, OW
+        d.conv.KH, d.conv.KW, d.conv.stride, d.conv.pad_h, d.conv.pad_w = KH, KW, stride, pad_h, pad_w
+        d.conv.OH, d.conv.OW = OH, OW
         Mv = a.numel() // (H * W * C) * OH * OW
         lda, sA, batch = 0, 0, 1
     else:
@@ -90,11 +91,12 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
 
 
 def conv_nhwc(x, w, KH, KW, stride, pad, **kw):
-    """x: [N,H,W,C] contiguous; w: [Cout, KH*KW*C] -> [N,OH,OW,Cout]."""
+    """x: [N,H,W,C] contiguous; w: [Cout, KH*KW*C] -> [N,OH,OW,Cout].  ``pad`` is an int or (pad_h, pad_w)."""
     n, H, W, C = x.shape
-    OH = (H + 2 * pad - KH) // stride + 1
-    OW = (W + 2 * pad - KW) // stride + 1
-    y = gemm_nt(x, w, conv=(H, W, C, KH, KW, stride, pad, OH, OW), **kw)
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    OH = (H + 2 * ph - KH) // stride + 1
+    OW = (W + 2 * pw - KW) // stride + 1
+    y = gemm_nt(x, w, conv=(H, W, C, KH, KW, stride, ph, pw, OH, OW), **kw)
     return y.view(n, OH, OW, w.shape[0])
 
 
@@ -184,12 +186,12 @@ def stem3d_fwd(video, weight, out_dtype, *, scale=None, shift=None, col_stats=No
     return out
 
 
-def maxpool3x3s2(x, *, scale=None, shift=None):
+def maxpool3x3s2(x, *, scale=None, shift=None, out_dtype=None):
     lib = _lib.load()
     N, H, W, C = x.shape
     OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-    y = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
-    check(lib.avsr_maxpool3x3s2(_stream(), _dt(x), x.data_ptr(), y.data_ptr(), _p(scale), _p(shift), N, H, W, C),
+    y = torch.empty((N, OH, OW, C), dtype=out_dtype or x.dtype, device=x.device)
+    check(lib.avsr_maxpool3x3s2(_stream(), _dt(x), _DT[y.dtype], x.data_ptr(), y.data_ptr(), _p(scale), _p(shift), N, H, W, C),
           "avsr_maxpool3x3s2")
     return y
 
@@ -219,12 +221,14 @@ def bn_fold(weight, bias, running_mean, running_var, eps=1e-5):
     return scale, shift
 
 
-def bn_apply(x, scale, shift, *, residual=None, relu=True, out=None):
+def bn_apply(x, scale, shift, *, residual=None, relu=True, out=None, out_dtype=None):
     lib = _lib.load()
     C = x.shape[-1]
-    y = out if out is not None else torch.empty_like(x)
-    check(lib.avsr_bn_apply(_stream(), _dt(x), x.data_ptr(), _p(residual), y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                            x.numel() // C, C, int(relu)), "avsr_bn_apply")
+    y = out if out is not None else torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    if residual is not None and residual.dtype != y.dtype:
+        raise TypeError("residual must have the output dtype")
+    check(lib.avsr_bn_apply(_stream(), _dt(x), _DT[y.dtype], x.data_ptr(), _p(residual), y.data_ptr(), scale.data_ptr(),
+                            shift.data_ptr(), x.numel() // C, C, int(relu)), "avsr_bn_apply")
     return y
 
 
@@ -245,7 +249,7 @@ def head_loss_fwd(logits, targets, input_lengths, target_lengths, label_smoothin
 
 
 def head_loss_bwd(logits, targets, input_lengths, target_lengths, ws, grad_dtype, *, label_smoothing=0.1,
-                  ignore_index=-100, blank=0, w_ctc=1.0, w_ce=1.0, upstream=None, ld_out=None):
+                  ignore_index=-100, blank=0, w_ctc=1.0, w_ce=1.0, up_ctc=None, up_ce=None, ld_out=None):
     lib = _lib.load()
     B, T, V = logits.shape
     ld = ld_out or V
@@ -255,7 +259,7 @@ def head_loss_bwd(logits, targets, input_lengths, target_lengths, ws, grad_dtype
     check(lib.avsr_head_loss_bwd(_stream(), _DT[grad_dtype], logits.data_ptr(), logits.stride(1), B, T, V,
                                  targets.data_ptr(), targets.stride(0), targets.shape[1], input_lengths.data_ptr(),
                                  target_lengths.data_ptr(), label_smoothing, ignore_index, blank, ws.data_ptr(), w_ctc,
-                                 w_ce, _p(upstream), buf.data_ptr(), ld), "avsr_head_loss_bwd")
+                                 w_ce, _p(up_ctc), _p(up_ce), buf.data_ptr(), ld), "avsr_head_loss_bwd")
     return buf
 
 
@@ -278,15 +282,20 @@ def cast(x, dtype, scale=1.0):
     return y
 
 
-def transpose2d(x, dtype=None, scale=1.0):
-    """[..., R, C] contiguous -> [..., C, R] contiguous (optionally converting dtype)."""
+def transpose2d(x, dtype=None, scale=1.0, pad_to=1):
+    """[..., R, C] (row-major, row stride may exceed C) -> [..., C, Rp] contiguous, Rp = R rounded up
+    to a multiple of ``pad_to`` with the padding columns zero (optionally converting dtype)."""
     lib = _lib.load()
-    x = x.contiguous()
+    if x.stride(-1) != 1 or (x.dim() > 2 and not x.is_contiguous()):
+        x = x.contiguous()
     R, C = x.shape[-2], x.shape[-1]
+    ldx = x.stride(-2)
+    Rp = (R + pad_to - 1) // pad_to * pad_to
     batch = x.numel() // (R * C)
-    y = torch.empty((*x.shape[:-2], C, R), dtype=dtype or x.dtype, device=x.device)
-    check(lib.avsr_transpose(_stream(), _dt(x), _DT[y.dtype], x.data_ptr(), C, R * C, y.data_ptr(), R, R * C, batch, R, C,
-                             scale), "avsr_transpose")
+    alloc = torch.zeros if Rp != R else torch.empty
+    y = alloc((*x.shape[:-2], C, Rp), dtype=dtype or x.dtype, device=x.device)
+    check(lib.avsr_transpose(_stream(), _dt(x), _DT[y.dtype], x.data_ptr(), ldx, R * ldx, y.data_ptr(), Rp, C * Rp, batch,
+                             R, C, scale), "avsr_transpose")
     return y
 
 

@@ -1,0 +1,209 @@
+"""Whisper encoder on the HIP kernels, plus the parameter containers that keep
+the reference's checkpoint key names (``whisper_model.encoder.*`` /
+``whisper_model.decoder.*``; the reference builds them with
+``WhisperModel.from_pretrained`` at models/av_net.py:22 and only ever runs the
+encoder, models/av_net.py:78-81).
+
+The encoder is frozen in the reference (models/av_net.py:25-26), so there is
+no backward here: ``WhisperEncoder.forward`` runs under ``no_grad``.
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+WHISPER_SIZES = {
+    # name: (d_model, layers, heads)  - ffn = 4*d_model, 80 mel bins, 1500 positions
+    "tiny": (384, 4, 6),
+    "base": (512, 6, 8),
+    "small": (768, 12, 12),
+    "medium": (1024, 24, 16),
+    "large-v2": (1280, 32, 20),
+}
+
+
+@dataclass
+class WhisperConfig:
+    d_model: int = 768
+    encoder_layers: int = 12
+    encoder_attention_heads: int = 12
+    decoder_layers: int = 12
+    decoder_attention_heads: int = 12
+    num_mel_bins: int = 80
+    max_source_positions: int = 1500
+    max_target_positions: int = 448
+    vocab_size: int = 51865
+    with_decoder: bool = True      # keep the (unused) decoder parameters for checkpoint compatibility
+
+    @property
+    def encoder_ffn_dim(self):
+        return 4 * self.d_model
+
+    @classmethod
+    def from_name(cls, name, **kw):
+        d, l, h = WHISPER_SIZES[name.replace("openai/whisper-", "")]
+        return cls(d_model=d, encoder_layers=l, encoder_attention_heads=h, decoder_layers=l,
+                   decoder_attention_heads=h, **kw)
+
+
+def sinusoids(length, channels, max_timescale=10000.0):
+    """Whisper's fixed encoder position table: [sin | cos] halves."""
+    inc = math.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2))
+    t = torch.arange(length).view(-1, 1) * inv.view(1, -1)
+    return torch.cat([t.sin(), t.cos()], dim=1)
+
+
+class _Attention(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj = nn.Linear(d, d, bias=False)
+        self.v_proj = nn.Linear(d, d)
+        self.q_proj = nn.Linear(d, d)
+        self.out_proj = nn.Linear(d, d)
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.self_attn = _Attention(d)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, 4 * d)
+        self.fc2 = nn.Linear(4 * d, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+class _DecoderLayer(nn.Module):
+    """Parameter container only: the reference never executes the decoder."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.self_attn = _Attention(d)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.encoder_attn = _Attention(d)
+        self.encoder_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, 4 * d)
+        self.fc2 = nn.Linear(4 * d, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+class WhisperDecoderParams(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        d = cfg.d_model
+        self.embed_tokens = nn.Embedding(cfg.vocab_size, d)
+        self.embed_positions = nn.Embedding(cfg.max_target_positions, d)
+        self.layers = nn.ModuleList([_DecoderLayer(d) for _ in range(cfg.decoder_layers)])
+        self.layer_norm = nn.LayerNorm(d)
+
+
+class WhisperEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        d = cfg.d_model
+        self.conv1 = nn.Conv1d(cfg.num_mel_bins, d, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv1d(d, d, kernel_size=3, stride=2, padding=1)
+        self.embed_positions = nn.Embedding(cfg.max_source_positions, d)
+        self.embed_positions.requires_grad_(False)
+        with torch.no_grad():
+            self.embed_positions.weight.copy_(sinusoids(cfg.max_source_positions, d))
+        self.layers = nn.ModuleList([_EncoderLayer(d) for _ in range(cfg.encoder_layers)])
+        self.layer_norm = nn.LayerNorm(d)
+        self._packed = None
+
+    # ---- weight packing -------------------------------------------------
+    def _versions(self, dtype):
+        return (dtype, sum(p._version for p in self.parameters()), next(self.parameters()).data_ptr())
+
+    def _pack(self, dtype):
+        """One-time (per weight version) repacking into what the kernels read:
+        conv weights as [out, tap*in], q/k/v fused into one [3D, D] matrix with the
+        head_dim**-0.5 query scaling folded into W_q and b_q (0.125: exact)."""
+        key = self._versions(dtype)
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+        d = self.cfg.d_model
+        hd = d // self.cfg.encoder_attention_heads
+        if hd != 64:
+            raise ValueError("attention kernels are built for head_dim 64")
+        s = hd ** -0.5
+        f32 = lambda t: t.detach().float().contiguous()
+        pk = {
+            "w1": self.conv1.weight.detach().permute(0, 2, 1).reshape(d, -1).to(dtype).contiguous(),
+            "b1": f32(self.conv1.bias),
+            "w2": self.conv2.weight.detach().permute(0, 2, 1).reshape(d, -1).to(dtype).contiguous(),
+            "b2": f32(self.conv2.bias),
+            "pos": f32(self.embed_positions.weight),
+            "lnf": (f32(self.layer_norm.weight), f32(self.layer_norm.bias)),
+            "layers": [],
+        }
+        for L in self.layers:
+            a = L.self_attn
+            wqkv = torch.cat([a.q_proj.weight.detach() * s, a.k_proj.weight.detach(), a.v_proj.weight.detach()], 0)
+            bqkv = torch.cat([a.q_proj.bias.detach() * s, torch.zeros_like(a.q_proj.bias), a.v_proj.bias.detach()], 0)
+            pk["layers"].append({
+                "ln1": (f32(L.self_attn_layer_norm.weight), f32(L.self_attn_layer_norm.bias)),
+                "wqkv": wqkv.to(dtype).contiguous(), "bqkv": f32(bqkv),
+                "wo": a.out_proj.weight.detach().to(dtype).contiguous(), "bo": f32(a.out_proj.bias),
+                "ln2": (f32(L.final_layer_norm.weight), f32(L.final_layer_norm.bias)),
+                "wfc1": L.fc1.weight.detach().to(dtype).contiguous(), "bfc1": f32(L.fc1.bias),
+                "wfc2": L.fc2.weight.detach().to(dtype).contiguous(), "bfc2": f32(L.fc2.bias),
+            })
+        self._packed = (key, pk)
+        return pk
+
+    # ---- forward ----------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, input_features, attention_mask=None, dtype=torch.bfloat16, channels_last=False):
+        """input_features: [B, n_mels, 3000] (the HF layout) or, with
+        ``channels_last``, [B, 3000, n_mels].  ``attention_mask`` is accepted and
+        ignored exactly as the HF encoder does (hf:607-609).  Returns a 1-tuple
+        ``([B, 1500, D] in the compute dtype,)`` so that ``encoder(x)[0]`` works."""
+        cfg = self.cfg
+        x = input_features
+        if not channels_last:
+            x = x.transpose(1, 2)
+        B, T, C = x.shape
+        expected = cfg.max_source_positions * 2
+        if T != expected or C != cfg.num_mel_bins:
+            raise ValueError(
+                f"Whisper expects the mel input features to be of length {expected}, but found {T}. "
+                f"Make sure to pad the input mel features to {expected}.")
+        pk = self._pack(dtype)
+        H, D = cfg.encoder_attention_heads, cfg.d_model
+        if channels_last:
+            xc = x if (x.dtype == dtype and x.is_contiguous()) else ops.cast(x, dtype)
+        else:                                   # [B, C, T] storage: transpose to channels-last on the way
+            xc = ops.transpose2d(input_features, dtype=dtype)
+        h1 = ops.conv_nhwc(xc.view(B, 1, T, C), pk["w1"], 1, 3, 1, (0, 1), bias=pk["b1"], act=ops.ACT_GELU)
+        Tn = cfg.max_source_positions
+        # gelu(conv2) + positions, written straight into the fp32 residual stream
+        xs = ops.conv_nhwc(h1, pk["w2"], 1, 3, 2, (0, 1), bias=pk["b2"], act=ops.ACT_GELU, residual=pk["pos"],
+                           res_period=Tn, out_dtype=torch.float32).view(B * Tn, D)
+        use_mfma = dtype == torch.bfloat16
+        for lw in pk["layers"]:
+            h = ops.layernorm_fwd(xs, *lw["ln1"], out_dtype=dtype)
+            qkv = ops.gemm_nt(h, lw["wqkv"], bias=lw["bqkv"]).view(B, Tn, 3 * D)
+            o = ops.attn_fwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H, scale=1.0, use_mfma=use_mfma)
+            ops.gemm_nt(o.view(B * Tn, D), lw["wo"], bias=lw["bo"], residual=xs, out=xs)
+            h = ops.layernorm_fwd(xs, *lw["ln2"], out_dtype=dtype)
+            f = ops.gemm_nt(h, lw["wfc1"], bias=lw["bfc1"], act=ops.ACT_GELU)
+            ops.gemm_nt(f, lw["wfc2"], bias=lw["bfc2"], residual=xs, out=xs)
+        out = ops.layernorm_fwd(xs, *pk["lnf"], out_dtype=dtype)
+        return (out.view(B, Tn, D),)
+
+
+class WhisperModel(nn.Module):
+    """Container with the HF attribute names the reference touches:
+    ``.encoder``, ``.decoder`` (parameters only) and ``.config.d_model``."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.encoder = WhisperEncoder(config)
+        if config.with_decoder:
+            self.decoder = WhisperDecoderParams(config)

@@ -1,0 +1,83 @@
+"""Shared test recipes: seeded weights for any state-dict layout and synthetic
+batches with the reference's batch schema (datamodule/data_module.py:142-152)."""
+import math
+
+import torch
+
+MODELARGS = (512, 8, 6, 3000, 2048, 0.1)     # config.py:12-17 -> (d_model, heads, layers, pe_max_len, fc_hidden, dropout)
+
+
+def seeded_values(shapes, seed=1234):
+    """Deterministic values for a {name: (shape, dtype)} layout, filled in sorted key
+    order from one CPU generator.  Scales keep activations O(1) through deep stacks;
+    gates are non-zero so the attention / FFN branches carry signal (they start at 0
+    in the reference, models/gate_cross_attention.py:19-20, which would hide them)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name in sorted(shapes):
+        shape, dtype = shapes[name]
+        if not dtype.is_floating_point:
+            out[name] = torch.zeros(shape, dtype=dtype)
+            continue
+        if name.endswith("running_var"):
+            v = torch.rand(shape, generator=g) + 0.5
+        elif name.endswith("running_mean"):
+            v = torch.randn(shape, generator=g) * 0.1
+        elif name.endswith("attn_gate"):
+            v = torch.full(shape, 0.6)
+        elif name.endswith("ff_gate"):
+            v = torch.full(shape, -0.4)
+        elif name.endswith("fusion_scalar"):
+            v = torch.ones(shape)
+        elif name.endswith(".pe") or name.endswith("embed_positions.weight") and "encoder" in name:
+            v = None                                  # fixed tables: keep the module's own values
+        elif len(shape) == 1:
+            is_norm_w = name.endswith("weight")       # 1-D weights are LayerNorm / BatchNorm gains
+            v = 1.0 + 0.1 * torch.randn(shape, generator=g) if is_norm_w else 0.05 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            v = torch.randn(shape, generator=g) * (1.0 / math.sqrt(fan_in))
+        if v is not None:
+            out[name] = v.to(dtype)
+    return out
+
+
+def seed_module(module, seed=1234):
+    """Load seeded values into a module in place; returns the resulting fp32 CPU state dict."""
+    sd = module.state_dict()
+    vals = seeded_values({k: (tuple(v.shape), v.dtype) for k, v in sd.items()}, seed)
+    module.load_state_dict(vals, strict=False)
+    return {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+
+
+def synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=1234, full_len=True):
+    """audio ~ N(0,1) [B,3000,80]; video ~ N(0,1) [B,Tv,3,H,W]; ragged video lengths with at
+    least one full-length item; targets in [1, vocab); CTC input length = Tv."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(max(1, Tv // 2), Tv + 1, (B,), generator=g)
+    if full_len:
+        lens[0] = Tv
+    video = torch.randn(B, Tv, 3, H, W, generator=g)
+    vmask = torch.arange(Tv).expand(B, Tv) < lens.unsqueeze(1)
+    video = video * vmask[:, :, None, None, None]             # padded frames are zeros (av_dataset.py pads with zeros)
+    return {
+        "audio": torch.randn(B, 3000, 80, generator=g),
+        "audio_mask": torch.ones(B, 3000, dtype=torch.bool),
+        "video": video,
+        "video_mask": vmask,
+        "video_lengths": lens,
+        "target_ids": torch.randint(1, vocab, (B, L), generator=g),
+        "target_lengths": torch.full((B, 1), L, dtype=torch.int64),
+        "audio_lengths": torch.full((B,), min(Tv, 1500), dtype=torch.int64),
+    }
+
+
+def to_device(batch, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def max_err(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1.0)).item()

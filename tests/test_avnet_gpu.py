@@ -1,0 +1,200 @@
+"""Module-level parity on the GPU: the HIP path of every reference class on the
+hot path against the CPU oracle, on identical seeded weights and inputs.
+
+Tolerances are the ones the task states: 1e-3 (fp32 compute) and 2e-2 (bf16
+compute), as max |got - ref| / max(1, max |ref|); greedy token ids must be
+bit-exact in fp32 (in bf16 they must agree wherever the reference's top-2
+margin exceeds the bf16 tolerance)."""
+import pytest
+import torch
+
+import oracle
+from mocov2_whisper_flamingo_amd import AVNet, GatedCrossModalFusion, MoCoVisualFrontend, WhisperConfig, WhisperModel
+from tests.helpers import max_err, seed_module, synthetic_batch, to_device
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
+MICRO = WhisperConfig(d_model=128, encoder_layers=2, encoder_attention_heads=2, decoder_layers=1,
+                      decoder_attention_heads=2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["micro", "tiny"])
+def test_whisper_encoder(dev, dtype, name):
+    cfg = MICRO if name == "micro" else WhisperConfig.from_name("tiny", with_decoder=False)
+    m = WhisperModel(cfg)
+    sd = seed_module(m, 7)
+    m.to(dev)
+    g = torch.Generator().manual_seed(3)
+    B = 2 if name == "micro" else 4            # 4 clips: the reference's CPU-runnable configuration
+    mel = torch.randn(B, 80, 3000, generator=g)
+    if name == "tiny":
+        mel[:, :, 1000:] = 0.0                 # 10 s clips zero-padded to 3000 frames
+    ref = oracle.whisper_encoder(sd, "encoder.", mel, cfg.encoder_attention_heads)
+    got = m.encoder(mel.to(dev), dtype=dtype)[0]
+    assert got.shape == ref.shape
+    assert max_err(got, ref) < TOL[dtype]
+    got2 = m.encoder(mel.transpose(1, 2).contiguous().to(dev), dtype=dtype, channels_last=True)[0]
+    assert max_err(got2, ref) < TOL[dtype]
+    with pytest.raises(ValueError):
+        m.encoder(mel[:, :, :2000].to(dev), dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("training", [False, True])
+def test_visual_frontend(dev, dtype, training):
+    m = MoCoVisualFrontend()
+    sd = seed_module(m, 11)
+    m.compute_dtype = dtype
+    m.to(dev).train(training)
+    g = torch.Generator().manual_seed(5)
+    B, T = 2, 8
+    video = torch.randn(B, T, 3, 64, 56, generator=g)
+    lens = torch.tensor([8, 3])
+    new_stats = {}
+    ref = oracle.visual_frontend(sd, "", video, lens, training, new_stats)
+    got = m(video.to(dev), lens.to(dev))
+    assert got.shape == ref.shape == (B, T, 2048)
+    assert max_err(got, ref) < TOL[dtype] * (2 if training else 1)
+    assert (got[1, 3:] == 0).all()
+    if training:   # running statistics follow nn.BatchNorm's momentum update
+        now = m.state_dict()
+        for k in ("frontend3D.1.running_mean", "MoCoModel.layer1.0.bn1.running_var", "MoCoModel.layer4.2.bn3.running_mean"):
+            assert max_err(now[k], new_stats[k]) < 5e-3 if dtype == torch.float32 else 5e-2
+        assert int(now["MoCoModel.layer2.0.downsample.1.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fusion_fwd_bwd(dev, dtype):
+    d, H, N = 512, 8, 3
+    m = GatedCrossModalFusion(d, H, N, dropout=0.1, dtype=dtype)
+    sd = seed_module(m, 13)
+    m.to(dev).eval()
+    g = torch.Generator().manual_seed(2)
+    B, T = 2, 75
+    a, v = torch.randn(B, T, d, generator=g), torch.randn(B, T, d, generator=g)
+    mask = torch.zeros(B, T, dtype=torch.bool)
+    mask[1, 40:] = True
+    names = [k for k in sd if sd[k].is_floating_point()]
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+    ar, vr = a.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    ref = oracle.fusion_forward(leaf, "", ar, vr, H, mask)
+    dout = torch.randn(B, T, d, generator=g)
+    ref.backward(dout)
+    ad = a.to(dev, dtype).requires_grad_(True)
+    vd = v.to(dev, dtype).requires_grad_(True)
+    got = m(ad, vd, None, mask.to(dev))
+    assert max_err(got, ref) < TOL[dtype]
+    got.backward(dout.to(dev, dtype))
+    assert max_err(ad.grad, ar.grad) < TOL[dtype] * 2
+    assert max_err(vd.grad, vr.grad) < TOL[dtype] * 2
+    params = dict(m.named_parameters())
+    for k in names:
+        assert params[k].grad is not None, k
+        assert max_err(params[k].grad, leaf[k].grad) < TOL[dtype] * 3, k
+
+
+def _micro_avnet(dtype, dev, vocab=503, p_drop=0.1):
+    m = AVNet("audiovisual", None, 96, (128, 2, 4, 3000, 512, p_drop), vocab, whisper_config=MICRO, dtype=dtype)
+    sd = seed_module(m, 21)
+    return m.to(dev), sd
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_avnet_forward_and_training_step(dev, dtype):
+    m, sd = _micro_avnet(dtype, dev)
+    m.eval()
+    batch = synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=99)
+    inp = (batch["audio"], batch["audio_mask"], batch["video"], batch["video_mask"], batch["video_lengths"].clone())
+    ref_logits, parts = oracle.avnet_forward(sd, inp, 2, 2, masked_row="zero", return_parts=True)
+    bd = to_device(batch, dev)
+    vl = bd["video_lengths"].clone()
+    logits = m((bd["audio"], bd["audio_mask"], bd["video"], bd["video_mask"], vl))
+    assert logits.shape == ref_logits.shape and logits.dtype == torch.float32
+    assert max_err(logits, ref_logits) < TOL[dtype]
+    ids, ref_ids = m.decode_ids(logits).cpu(), ref_logits.argmax(-1)
+    if dtype == torch.float32:
+        assert torch.equal(ids, ref_ids)
+    else:
+        top2 = ref_logits.topk(2, -1).values
+        sure = (top2[..., 0] - top2[..., 1]) > 2 * TOL[dtype] * ref_logits.abs().max()
+        assert torch.equal(ids[sure], ref_ids[sure])
+    # [B,80,3000] input layout gives the same result
+    logits2 = m((bd["audio"].transpose(1, 2).contiguous(), bd["audio_mask"], bd["video"], bd["video_mask"],
+                 bd["video_lengths"].clone()))
+    assert max_err(logits2, ref_logits) < TOL[dtype]
+
+    # training step (eval-mode BN and no dropout so the CPU path is comparable): loss and every gradient
+    loss_r, ctc_r, ce_r, _, grads_r, _ = oracle.training_step(sd, batch, 2, 2, masked_row="zero")
+    loss, ctc, ce, lg = m.training_step(bd)
+    assert abs(loss.item() - loss_r.item()) < TOL[dtype] * max(1.0, abs(loss_r.item()))
+    assert abs(ctc.item() - ctc_r.item()) < TOL[dtype] * max(1.0, abs(ctc_r.item()))
+    assert abs(ce.item() - ce_r.item()) < TOL[dtype] * max(1.0, abs(ce_r.item()))
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k, gr in grads_r.items():
+        assert params[k].grad is not None, k
+        scale = max(1.0, gr.abs().max().item())
+        assert (params[k].grad.float().cpu() - gr).abs().max().item() < TOL[dtype] * 5 * scale, k
+    # the frozen encoders and the parameters the reference never reaches have no gradient
+    assert all(p.grad is None for n, p in params.items() if n.startswith(("whisper_model.", "visual_model.")))
+    assert params["fusion_scalar"].grad is None
+
+
+def test_avnet_generic_loss_backward(dev):
+    """Drop-in use: the caller puts its own torch loss on the returned logits."""
+    dtype = torch.float32
+    m, sd = _micro_avnet(dtype, dev)
+    m.eval()
+    batch = synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=5)
+    bd = to_device(batch, dev)
+    logits = m((bd["audio"], bd["audio_mask"], bd["video"], bd["video_mask"], bd["video_lengths"].clone()))
+    import torch.nn.functional as F
+    lp = F.log_softmax(logits, -1).transpose(0, 1)
+    ctc = F.ctc_loss(lp, bd["target_ids"], bd["audio_lengths"], bd["target_lengths"].reshape(-1), blank=0,
+                     reduction="mean", zero_infinity=True)
+    ce = F.cross_entropy(logits[:, :4].reshape(-1, 503), bd["target_ids"].reshape(-1), label_smoothing=0.1)
+    (ctc + ce).backward()
+    _, _, _, _, grads_r, _ = oracle.training_step(sd, batch, 2, 2, masked_row="zero")
+    params = dict(m.named_parameters())
+    for k, gr in grads_r.items():
+        scale = max(1.0, gr.abs().max().item())
+        assert (params[k].grad.float().cpu() - gr).abs().max().item() < 5e-3 * scale, k
+
+
+def test_video_len_clamped_in_place_and_all_masked(dev):
+    m, sd = _micro_avnet(torch.float32, dev)
+    m.eval()
+    batch = synthetic_batch(B=2, Tv=6, H=32, W=32, seed=1)
+    bd = to_device(batch, dev)
+    vl = torch.tensor([9, 0], device=dev)       # longer than the clip, and an empty clip (every key masked)
+    logits = m((bd["audio"], bd["audio_mask"], bd["video"], bd["video_mask"], vl))
+    assert vl.tolist() == [6, 0]
+    assert torch.isfinite(logits).all()
+
+
+def test_train_mode_dropout_replay(dev):
+    """Train mode: batch-norm batch statistics + dropout.  The device generator is replayed on
+    the host so the CPU path sees the same keep masks."""
+    from tests.philox_ref import keep_mask
+    dtype = torch.float32
+    m, sd = _micro_avnet(dtype, dev, p_drop=0.2)
+    m.train()
+    batch = synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=17)
+    bd = to_device(batch, dev)
+    loss, ctc, ce, logits = m.training_step(bd)
+    B, T, H, d, p = 2, 6, 2, 128, 0.2
+    drop = {"attn": [], "ff": []}
+    for i in range(2):
+        drop["attn"].append(torch.from_numpy(keep_mask(m._dropout_seed(f"fusion.{i}.attn"), (B, H, T, T), p)))
+        drop["ff"].append(torch.from_numpy(keep_mask(m._dropout_seed(f"fusion.{i}.ff"), (B * T, d), p)).view(B, T, d))
+    loss_r, _, _, logits_r, grads_r, _ = oracle.training_step(sd, batch, 2, 2, training=True, drop=drop, p_drop=p,
+                                                                masked_row="zero")
+    assert max_err(logits, logits_r) < 2e-3
+    assert abs(loss.item() - loss_r.item()) < 2e-3 * max(1.0, abs(loss_r.item()))
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k, gr in grads_r.items():
+        scale = max(1.0, gr.abs().max().item())
+        assert (params[k].grad.float().cpu() - gr).abs().max().item() < 1e-2 * scale, k

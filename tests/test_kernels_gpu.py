@@ -104,10 +104,11 @@ def test_conv_implicit_gemm(dev, dtype, cfg):
     x = rnd(g, n, C, H, W, dtype=dtype)
     w = rnd(g, Co, C, KH, KW, dtype=dtype, scale=1.0 / math.sqrt(C * KH * KW))
     bias = torch.randn(Co, generator=g)
-    ref = F.relu(F.conv2d(x, w, bias, stride=s, padding=p)).permute(0, 2, 3, 1)
+    pad = (0, p) if H == 1 else p
+    ref = F.relu(F.conv2d(x, w, bias, stride=s, padding=pad)).permute(0, 2, 3, 1)
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev, dtype)
     wd = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous().to(dev, dtype)
-    out = ops.conv_nhwc(xd, wd, KH, KW, s, p, out_dtype=torch.float32, bias=bias.to(dev), act=ops.ACT_RELU)
+    out = ops.conv_nhwc(xd, wd, KH, KW, s, pad, out_dtype=torch.float32, bias=bias.to(dev), act=ops.ACT_RELU)
     assert out.shape == ref.shape
     assert rel_err(out, ref) < tol(dtype)
 
@@ -222,11 +223,11 @@ def test_stem_pool_bn(dev, odt):
     ref_t = F.max_pool3d(F.relu(F.batch_norm(conv, rm2, rv2, bw, bb, True)), (1, 3, 3), (1, 2, 2), (0, 1, 1))
     ref_t = ref_t.permute(0, 2, 3, 4, 1).reshape(B * T, ref.shape[1], ref.shape[2], 64)
     cs = torch.zeros(2, 64, device=dev)
-    raw = ops.stem3d_fwd(video.to(dev), w.to(dev), odt, col_stats=(cs[0], cs[1]))
+    raw = ops.stem3d_fwd(video.to(dev), w.to(dev), torch.float32, col_stats=(cs[0], cs[1]))
     rmd, rvd = rm.to(dev), rv.to(dev)
     sc2, sh2 = torch.empty(64, device=dev), torch.empty(64, device=dev)
     ops.bn_finalize(cs[0], cs[1], raw.numel() // 64, bw.to(dev), bb.to(dev), rmd, rvd, sc2, sh2)
-    out_t = ops.maxpool3x3s2(raw, scale=sc2, shift=sh2)
+    out_t = ops.maxpool3x3s2(raw, scale=sc2, shift=sh2, out_dtype=odt)
     assert rel_err(out_t, ref_t) < tol(odt) * 2
     assert rel_err(rmd, rm2) < 1e-3 and rel_err(rvd, rv2) < 1e-3
     # bn_apply with residual
