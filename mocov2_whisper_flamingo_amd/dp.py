@@ -1,0 +1,171 @@
+"""Data-parallel training runtime: flat parameter / gradient buffers, bucketed
+gradient all-reduce over RCCL overlapped with the backward pass, global-norm
+clipping and one fused AdamW launch.
+
+This is the MI355X counterpart of what the reference gets implicitly from
+Lightning's ``DDPStrategy(find_unused_parameters=True)`` + ``gradient_clip_val``
++ ``torch.optim.AdamW`` (train.py:218-225,312-322).  Differences by design:
+
+* only parameters that can receive a gradient are registered (the reference's
+  buckets also carry the 153.6 M never-used Whisper-decoder weights and
+  ``fusion_scalar``; AdamW skips ``grad is None`` parameters, so leaving them out
+  changes no result and removes 80 % of the all-reduce volume);
+* gradients live in ONE flat fp32 buffer cut into a few large buckets ordered
+  the way backward produces them (head first), so each bucket is one RCCL
+  all-reduce on a side stream that starts while the rest of backward still
+  runs; xGMI is a point-to-point mesh, so few large messages beat many small ones;
+* clipping needs no extra collective: after the all-reduce every rank holds the
+  same averaged gradient and computes the same norm locally.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def trainable_parameters(model):
+    """(name, parameter) pairs autograd reaches in AVNet, in registration order."""
+    skip = ("whisper_model.", "visual_model.")
+    return [(n, p) for n, p in model.named_parameters()
+            if p.requires_grad and not n.startswith(skip) and n != "fusion_scalar"]
+
+
+class FlatTrainer:
+    """Owns flat fp32 parameter / gradient / AdamW-moment buffers for the trainable
+    tail of an AVNet and runs reduce -> clip -> AdamW on them.
+
+    Works with or without an initialised process group (world size 1: no collective).
+    """
+
+    def __init__(self, model, *, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_grad_norm=1.0,
+                 bucket_mb=64, process_group=None, overlap=True):
+        self.model = model
+        self.named = trainable_parameters(model)
+        if not self.named:
+            raise ValueError("model has no trainable parameters")
+        dev = self.named[0][1].device
+        self.device = dev
+        self.on_gpu = dev.type == "cuda"
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.step_count = 0
+
+        # backward reaches parameters roughly in reverse registration order: lay the flat buffer out in
+        # that order so buckets fill front to back as backward proceeds
+        order = list(reversed(self.named))
+        sizes = [p.numel() for _, p in order]
+        # 16-byte alignment for every parameter view
+        offs, total = [], 0
+        for s in sizes:
+            offs.append(total)
+            total += (s + 3) // 4 * 4
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.slices = {}
+        with torch.no_grad():
+            for (n, p), o, s in zip(order, offs, sizes):
+                self.flat_param[o:o + s].copy_(p.detach().reshape(-1))
+                p.data = self.flat_param[o:o + s].view(p.shape)
+                p.grad = self.flat_grad[o:o + s].view(p.shape)
+                self.slices[n] = (o, s)
+        # buckets: contiguous element ranges of about bucket_mb each
+        cap = max(1, int(bucket_mb * 1024 * 1024 // 4))
+        self.buckets, start, pending = [], 0, []
+        for (n, p), o, s in zip(order, offs, sizes):
+            pending.append(p)
+            end = o + (s + 3) // 4 * 4
+            if end - start >= cap:
+                self.buckets.append({"range": (start, end), "params": pending, "left": 0})
+                start, pending = end, []
+        if pending:
+            self.buckets.append({"range": (start, total), "params": pending, "left": 0})
+        self._bucket_of = {id(p): b for b in self.buckets for p in b["params"]}
+        self.overlap = overlap and self.world > 1
+        self.comm_stream = torch.cuda.Stream(device=dev) if (self.on_gpu and self.world > 1) else None
+        self._works = []
+        if self.overlap:
+            for _, p in self.named:
+                p.register_post_accumulate_grad_hook(self._on_grad_ready)
+        self._scratch = torch.zeros(3, dtype=torch.float32, device=dev)   # sumsq, clip scale, norm
+        self._arm()
+
+    # ---- gradient reduction -------------------------------------------------
+    def _arm(self):
+        for b in self.buckets:
+            b["left"] = len(b["params"])
+
+    def _reduce_bucket(self, b):
+        lo, hi = b["range"]
+        view = self.flat_grad[lo:hi]
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append(w)
+
+    def _on_grad_ready(self, p):
+        b = self._bucket_of[id(p)]
+        b["left"] -= 1
+        if b["left"] == 0:
+            self._reduce_bucket(b)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for n, p in self.named:          # keep .grad pointing into the flat buffer
+            if p.grad is None:
+                o, s = self.slices[n]
+                p.grad = self.flat_grad[o:o + s].view(p.shape)
+        self._arm()
+
+    def reduce_gradients(self):
+        """Finish the all-reduce of every bucket (launching those the hooks did not) and
+        turn the sums into means."""
+        if self.world == 1:
+            return
+        for b in self.buckets:
+            if not self.overlap or b["left"] > 0:     # unused parameter in the bucket, or no hooks
+                self._reduce_bucket(b)
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.flat_grad.mul_(1.0 / self.world)
+
+    # ---- optimizer ----------------------------------------------------------
+    def step(self, lr=None):
+        """Global-norm clip (train.py:321) + AdamW (train.py:219-225) on the flat buffers."""
+        self.step_count += 1
+        lr = self.lr if lr is None else lr
+        scr = self._scratch
+        scr.zero_()
+        ops.sumsq_accumulate(self.flat_grad, scr[0:1])
+        ops.clip_scale(scr[0:1], self.max_norm, scr[1:2], scr[2:3])
+        ops.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, lr=lr,
+                       betas=self.betas, eps=self.eps, weight_decay=self.wd, grad_scale=scr[1:2])
+        # parameters changed in place behind torch's back: drop the compute-dtype weight copies
+        cache = getattr(self.model, "_cache", None)
+        if cache is not None:
+            cache.bump()
+        return scr[2:3]
+
+    def grad_norm(self):
+        return self._scratch[2:3]
+
+
+def one_cycle_lr(step, total_steps, max_lr=1e-3, pct_start=0.1, div_factor=25.0, final_div_factor=1e4):
+    """torch.optim.lr_scheduler.OneCycleLR(anneal_strategy='linear', three_phase=False) as configured
+    at train.py:230-238: the learning rate to use for optimizer step number ``step`` (0-based)."""
+    initial, min_lr = max_lr / div_factor, max_lr / div_factor / final_div_factor
+    up_end = float(pct_start * total_steps) - 1.0
+    down_end = float(total_steps) - 1.0
+    if step <= up_end:
+        pct = step / up_end if up_end > 0 else 1.0
+        return initial + pct * (max_lr - initial)
+    pct = (step - up_end) / (down_end - up_end)
+    return max_lr + pct * (min_lr - max_lr)

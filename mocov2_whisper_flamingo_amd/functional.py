@@ -20,11 +20,16 @@ class WeightCache:
     def __init__(self, dtype):
         self.dtype = dtype
         self._store = {}
+        self.epoch = 0
+
+    def bump(self):
+        """Invalidate every copy (the weights were updated in place outside autograd)."""
+        self.epoch += 1
 
     def get(self, p):
         key = id(p)
         hit = self._store.get(key)
-        ver = (p._version, p.data_ptr())
+        ver = (p._version, p.data_ptr(), self.epoch)
         if hit is not None and hit[0] == ver:
             return hit[1], hit[2]
         with torch.no_grad():

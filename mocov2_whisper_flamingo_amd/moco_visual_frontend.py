@@ -74,6 +74,7 @@ class MoCoVisualFrontend(nn.Module):
         self.MoCoModel = _ResNet50Trunk()
         self.compute_dtype = torch.bfloat16
         self._packed = None
+        self._blocks = list(self.MoCoModel.blocks())
 
     # ---- weight packing -------------------------------------------------
     def _pack(self, dtype):
@@ -122,36 +123,47 @@ class MoCoVisualFrontend(nn.Module):
         return ops.bn_apply(raw, sc, sh, residual=residual, relu=relu, out_dtype=x.dtype)
 
     @torch.no_grad()
+    def run_stem(self, video):
+        """frontend3D on fp32 video [B,T,3,H,W] -> NHWC [B*T, H/4, W/4, 64] in the compute dtype."""
+        dtype = self.compute_dtype
+        pk = self._pack(dtype)
+        bn0 = self.frontend3D[1]
+        if not self.training:
+            sc, sh = self._fold(bn0)
+            return ops.maxpool3x3s2(ops.stem3d_fwd(video, pk["stem_w"], dtype, scale=sc, shift=sh))
+        stats = torch.zeros((2, 64), dtype=torch.float32, device=video.device)
+        raw = ops.stem3d_fwd(video, pk["stem_w"], torch.float32, col_stats=(stats[0], stats[1]))
+        sc = torch.empty(64, dtype=torch.float32, device=video.device)
+        sh = torch.empty(64, dtype=torch.float32, device=video.device)
+        ops.bn_finalize(stats[0], stats[1], raw.numel() // 64, bn0.weight.detach(), bn0.bias.detach(),
+                        bn0.running_mean, bn0.running_var, sc, sh, bn0.eps, bn0.momentum)
+        return ops.maxpool3x3s2(raw, scale=sc, shift=sh, out_dtype=dtype)
+
+    @torch.no_grad()
+    def run_block(self, index, y):
+        """One Bottleneck (index 0..15 over layer1..layer4) on an NHWC tensor."""
+        pk = self._pack(self.compute_dtype)
+        e = pk["blocks"][index]
+        blk = self._blocks[index]
+        idt = y
+        if "wd" in e:
+            idt = self._conv_bn(y, e["wd"], 1, e["stride"], 0, blk.downsample[1], relu=False)
+        h = self._conv_bn(y, e["w1"], 1, 1, 0, blk.bn1, relu=True)
+        h = self._conv_bn(h, e["w2"], 3, e["stride"], 1, blk.bn2, relu=True)
+        return self._conv_bn(h, e["w3"], 1, 1, 0, blk.bn3, relu=True, residual=idt)
+
+    @torch.no_grad()
     def forward(self, x, x_len):
         """x: [B,T,3,H,W] (or [B,1,T,3,H,W]) fp32, x_len: int64 [B] -> [B,T,2048]
         in the compute dtype, rows t >= x_len[b] zero."""
         if x.dim() == 6 and x.shape[1] == 1:
             x = x.squeeze(1)
-        dtype = self.compute_dtype
-        pk = self._pack(dtype)
         B, T = x.shape[0], x.shape[1]
         video = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
-        bn0 = self.frontend3D[1]
-        if not self.training:
-            sc, sh = self._fold(bn0)
-            y = ops.stem3d_fwd(video, pk["stem_w"], dtype, scale=sc, shift=sh)
-            y = ops.maxpool3x3s2(y)
-        else:
-            stats = torch.zeros((2, 64), dtype=torch.float32, device=x.device)
-            raw = ops.stem3d_fwd(video, pk["stem_w"], torch.float32, col_stats=(stats[0], stats[1]))
-            sc = torch.empty(64, dtype=torch.float32, device=x.device)
-            sh = torch.empty(64, dtype=torch.float32, device=x.device)
-            ops.bn_finalize(stats[0], stats[1], raw.numel() // 64, bn0.weight.detach(), bn0.bias.detach(),
-                            bn0.running_mean, bn0.running_var, sc, sh, bn0.eps, bn0.momentum)
-            y = ops.maxpool3x3s2(raw, scale=sc, shift=sh, out_dtype=dtype)
-        for blk, e in zip(self.MoCoModel.blocks(), pk["blocks"]):
-            idt = y
-            if "wd" in e:
-                idt = self._conv_bn(y, e["wd"], 1, e["stride"], 0, blk.downsample[1], relu=False)
-            h = self._conv_bn(y, e["w1"], 1, 1, 0, blk.bn1, relu=True)
-            h = self._conv_bn(h, e["w2"], 3, e["stride"], 1, blk.bn2, relu=True)
-            y = self._conv_bn(h, e["w3"], 1, 1, 0, blk.bn3, relu=True, residual=idt)
+        y = self.run_stem(video)
+        for i in range(len(self._blocks)):
+            y = self.run_block(i, y)
         if self.training:   # one fused increment for all 54 counters
             torch._foreach_add_([m.num_batches_tracked for m in self.modules()
                                  if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d))], 1)
-        return ops.avgpool_mask(y, x_len, B, T, dtype)
+        return ops.avgpool_mask(y, x_len, B, T, self.compute_dtype)

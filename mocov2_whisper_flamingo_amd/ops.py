@@ -11,6 +11,10 @@ from ._lib import F32, BF16, ACT_NONE, ACT_GELU, ACT_RELU, ACT_RELU_AFTER_RESIDU
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
+# When set to a list, every gemm_nt launch appends (start_event, end_event, flops, tag): HIP events
+# recorded on the launch stream, used by bench.py to time the dominant kernel per launch.
+GEMM_PROFILE = None
+
 
 def _dt(t):
     try:
@@ -86,7 +90,14 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
     d.gate = _p(gate)
     if col_stats is not None:
         d.col_sum, d.col_sumsq = col_stats[0].data_ptr(), col_stats[1].data_ptr()
+    if GEMM_PROFILE is None:
+        check(lib.avsr_gemm_nt(_stream(), ctypes.byref(d)), "avsr_gemm_nt")
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib.avsr_gemm_nt(_stream(), ctypes.byref(d)), "avsr_gemm_nt")
+    e1.record()
+    GEMM_PROFILE.append((e0, e1, 2.0 * Mv * N * K * batch, "bf16" if a.dtype == torch.bfloat16 else "f32"))
     return out
 
 
