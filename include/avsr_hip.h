@@ -49,8 +49,8 @@ const char* avsr_version(void);
  * epilogue, in this order:  v = acc * alpha;  v *= scale[n];  v += bias[n];
  *   v = act(v);  v = residual[m,n] + g * v  (g = tanh(*gate) or 1);
  *   (AVSR_ACT_RELU_AFTER_RESIDUAL applies the ReLU after the residual add;)
- *   optional per-column sums of the PRE-activation value into col_sum /
- *   col_sumsq (fp32 atomics) for batch-norm statistics.
+ *   optional per-column partial sums of the PRE-activation value into the
+ *   col_sum / col_sumsq slabs for batch-norm statistics.
  *
  * conv mode (conv.enabled): A is an NHWC image [n_img,H,W,C]; row m of the
  * implicit A matrix is output pixel (img,oh,ow), column k = (kh*KW+kw)*C + c;
@@ -74,8 +74,8 @@ typedef struct {
     int64_t ldr;
     int64_t res_period;   /* > 0: residual row = m % res_period (a [period,N] table, e.g. positions) */
     const float* gate;    /* device scalar or NULL */
-    float* col_sum;       /* [N] or NULL */
-    float* col_sumsq;     /* [N] or NULL */
+    float* col_sum;       /* [avsr_gemm_stats_parts(), N] partial sums, or NULL */
+    float* col_sumsq;     /* same shape, partial sums of squares */
     struct {
         int32_t enabled;
         int32_t H, W, C, KH, KW, stride, pad_h, pad_w, OH, OW;
@@ -83,6 +83,9 @@ typedef struct {
 } avsr_gemm_t;
 
 int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g);
+/* rows of the [parts, N] col_sum / col_sumsq slabs a launch with M rows fills
+ * (one row per producing workgroup / wave: plain stores, deterministic) */
+int64_t avsr_gemm_stats_parts(int in_dtype, int64_t M);
 
 /* ------------------------------------------------------------------------
  * LayerNorm over the last dimension, one wave per row, fp32 statistics.
@@ -127,10 +130,11 @@ int avsr_attn_bwd(avsr_stream_t stream, int dtype, const void* Q, int64_t ldq, c
 /* ------------------------------------------------------------------------
  * Visual frontend pieces (models/moco_visual_frontend.py).
  * avsr_stem3d_fwd: Conv3d(3,64,(5,3,3),s(1,2,2),p(2,3,3),bias=False) (:15) on
- *   video [B,T,3,H,W] fp32 -> NHWC [B*T,OH,OW,64].  With scale/shift the
- *   eval-mode BatchNorm3d + ReLU (:16-17) are folded in; otherwise the raw
- *   convolution is stored and per-channel sum / sum-of-squares accumulate
- *   into col_sum / col_sumsq (training-mode batch statistics).
+ *   video [B,T,3,H,W] fp32 -> NHWC [B*T,OH,OW,64]; weight_packed is the
+ *   weight transposed to [135 taps][64].  With scale/shift the eval-mode
+ *   BatchNorm3d + ReLU (:16-17) are folded in; otherwise the raw convolution
+ *   is stored and per-workgroup channel sums / sums of squares go to the
+ *   [avsr_stem3d_stats_parts(), 64] slabs (training-mode batch statistics).
  * avsr_maxpool3x3s2: MaxPool3d((1,3,3),(1,2,2),(0,1,1)) (:18) over NHWC, with
  *   an optional per-channel affine + ReLU applied to each element first.
  * avsr_avgpool_mask_fwd: AdaptiveAvgPool2d(1) of the trunk + masked_fill of
@@ -138,16 +142,20 @@ int avsr_attn_bwd(avsr_stream_t stream, int dtype, const void* Q, int64_t ldq, c
  * avsr_bn_*: BatchNorm2d/3d in training mode (batch statistics -> affine,
  *   running-stat update with the unbiased variance) and eval mode (fold).
  * ---------------------------------------------------------------------- */
-int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float* video, const float* weight, void* out,
-                    const float* scale, const float* shift, float* col_sum, float* col_sumsq, int64_t B,
-                    int64_t T, int64_t H, int64_t W);
+int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float* video, const float* weight_packed,
+                    void* out, const float* scale, const float* shift, float* col_sum, float* col_sumsq,
+                    int64_t B, int64_t T, int64_t H, int64_t W);
+int64_t avsr_stem3d_stats_parts(int64_t B, int64_t T, int64_t H, int64_t W);
 int avsr_maxpool3x3s2(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y,
                       const float* scale, const float* shift, int64_t N, int64_t H, int64_t W, int64_t C);
 int avsr_avgpool_mask_fwd(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y,
                           const int64_t* lens, int64_t B, int64_t T, int64_t HW, int64_t C);
-int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq, double count,
+/* sum / sumsq: [nparts, C] partial-sum slabs; ws: avsr_bn_finalize_workspace_floats(C) floats,
+ * needed when nparts > 32 */
+int64_t avsr_bn_finalize_workspace_floats(int64_t C);
+int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq, int64_t nparts, double count,
                      const float* weight, const float* bias, float* running_mean, float* running_var,
-                     float* scale, float* shift, int64_t C, float eps, float momentum);
+                     float* scale, float* shift, int64_t C, float eps, float momentum, float* ws);
 int avsr_bn_fold(avsr_stream_t stream, const float* weight, const float* bias, const float* running_mean,
                  const float* running_var, float* scale, float* shift, int64_t C, float eps);
 /* y = act(x*scale + shift (+ residual)); x may be fp32 while y / residual are bf16 */

@@ -1,8 +1,7 @@
 // NT GEMM with fused epilogue and an implicit-GEMM (NHWC conv) A-operand
 // loader.  Two kernels:
-//   * bf16 inputs: 128x128x64 tile, 4 waves (2x2), 64x64 per wave as 4x4
-//     v_mfma_f32_16x16x32_bf16, register-staged global->LDS double buffering,
-//     XOR-swizzled 128-byte LDS rows read with ds_read_b128.
+//   * bf16 inputs: 128x128x32 (or 128x64x32) tile, 4 waves, v_mfma_f32_16x16x32_bf16,
+//     operands DMA'd global->LDS into a 4-stage ring with a counted vmcnt.
 //   * f32 inputs: 64x64x16 tile on v_mfma_f32_16x16x4_f32 (exact fp32 fma
 //     chain) - the reference-precision path used for fp32 parity.
 // The weight operand B feeds the MFMA "A" slot, so an accumulator register
@@ -125,135 +124,259 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, f32x4 acc, int m, 
 }
 
 // Column sums of the pre-activation values over the valid rows of this wave's
-// sub-tile; one atomic per column per wave.
-__device__ __forceinline__ void stats_quad(const GemmP& p, f32x4 s, f32x4 s2, int nb, int lane) {
+// sub-tile, stored (no atomics, deterministic) into row `part` of the [parts, N] slabs.
+__device__ __forceinline__ void stats_quad(const GemmP& p, f32x4 s, f32x4 s2, int nb, int lane, int part) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float a = s[r], b = s2[r];
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
         if ((lane & 15) == 0 && nb + r < p.N) {
-            atomicAdd(p.csum + nb + r, a);
-            atomicAdd(p.csq + nb + r, b);
+            p.csum[(long)part * p.N + nb + r] = a;
+            p.csq[(long)part * p.N + nb + r] = b;
+        }
+    }
+}
+
+// Epilogue of the bf16 kernel: the accumulators go through an LDS tile (two passes of 64 rows)
+// so that every thread owns 8 consecutive columns of a row: scale / bias are loaded once per
+// thread, residual reads and output stores are 16-byte (bf16) or 2 x 16-byte (fp32) and a row
+// segment of the tile is written by consecutive lanes.  Column statistics are reduced per block
+// and stored into row `tm` of the [tiles_m, N] slabs.
+template <int BN_, typename OutT>
+__device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[4][BN_ / 32], char* lds, int m0, int n0,
+                                              int tm, long cbase, int lane, int wave) {
+    constexpr int NJ = BN_ / 32, LDT = BN_ + 4, CG = BN_ / 8, RS = 256 / CG;
+    float* Ct = (float*)lds;
+    float* red = Ct + 64 * LDT;                 // [4][2][BN_] per-wave column partials
+    const int wm = wave >> 1, wn = wave & 1;
+    const int t = threadIdx.x;
+    const int cg = t % CG, r0 = t / CG;
+    const int n = n0 + cg * 8;
+    const float g = p.gate ? tanhf(*p.gate) : 1.0f;
+    float sc[8], bi[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bool in = n + e < p.N;
+        sc[e] = (p.scale && in) ? p.scale[n + e] : 1.f;
+        bi[e] = (p.bias && in) ? p.bias[n + e] : 0.f;
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+    const bool post_relu = p.act == AVSR_ACT_RELU_AFTER_RESIDUAL;
+    const bool full = p.vec_ok && n + 7 < p.N;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                *(f32x4*)&Ct[(wm * 32 + ii * 16 + (lane & 15)) * LDT + (wn * NJ + j) * 16 + (lane >> 4) * 4] = acc[2 * h + ii][j];
+        __syncthreads();
+        for (int lr = r0; lr < 64; lr += RS) {
+            const int m = m0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+            if (m >= p.M) continue;
+            const f32x4 c0 = *(const f32x4*)&Ct[lr * LDT + cg * 8], c1 = *(const f32x4*)&Ct[lr * LDT + cg * 8 + 4];
+            float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = v[e] * p.alpha * sc[e] + bi[e];
+                s1[e] += x; s2[e] += x * x;
+                if (p.act == AVSR_ACT_GELU) x = gelu_erf(x);
+                else if (p.act == AVSR_ACT_RELU) x = fmaxf(x, 0.f);
+                v[e] = x;
+            }
+            OutT* cp = (OutT*)p.C + cbase + (long)m * p.ldc + n;
+            const OutT* rp = p.res ? (const OutT*)p.res + (long)(p.res_period > 0 ? m % p.res_period : m) * p.ldr + n : nullptr;
+            if (full) {
+                if (rp) {
+                    if constexpr (sizeof(OutT) == 4) {
+                        const f32x4 ra = *(const f32x4*)rp, rb = *(const f32x4*)(rp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = ra[e] + g * v[e]; v[4 + e] = rb[e] + g * v[4 + e]; }
+                    } else {
+                        const bf16x8 rv = *(const bf16x8*)rp;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (float)rv[e] + g * v[e];
+                    }
+                }
+                if (post_relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if constexpr (sizeof(OutT) == 4) {
+                    *(f32x4*)cp = (f32x4){v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                    *(bf16x8*)cp = o;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (n + e < p.N) {
+                        float x = v[e];
+                        if (rp) x = to_f32<OutT>(rp[e]) + g * x;
+                        if (post_relu) x = fmaxf(x, 0.f);
+                        cp[e] = from_f32<OutT>(x);
+                    }
+                }
+            }
+        }
+    }
+    if (p.csum) {
+        // lanes with equal (lane % CG) own the same columns: fold them, then the 4 waves through LDS
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = CG; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+        }
+        if (lane < CG) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * 2 + 0) * BN_ + lane * 8 + e] = s1[e];
+                red[(wave * 2 + 1) * BN_ + lane * 8 + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (t < BN_ && n0 + t < p.N) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += red[(w * 2 + 0) * BN_ + t]; b += red[(w * 2 + 1) * BN_ + t]; }
+            p.csum[(long)tm * p.N + n0 + t] = a;
+            p.csq[(long)tm * p.N + n0 + t] = b;
         }
     }
 }
 
 // ---------------------------------------------------------------- bf16 ----
-#define BM 128
-#define BN 128
-#define BK 64
+// 128 x BN x 32 tiles, 4 waves, v_mfma_f32_16x16x32_bf16.  Operand tiles go
+// global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction)
+// into a 4-stage ring; three K-steps of loads stay in flight across the raw
+// s_barrier behind a counted s_waitcnt vmcnt, so HBM/L2 latency is covered by
+// three compute phases plus the second resident workgroup of the CU.
+//
+// LDS image: one 1-KiB "piece" per 16-row sub-tile, laid out in FRAGMENT order:
+// byte 16*l of a piece holds (row l&15, k-chunk l>>4), exactly the 8 bf16 lane l
+// feeds to the MFMA.  The DMA writes lane-linear, the ds_read_b128 reads
+// lane-linear: both conflict-free, no swizzle arithmetic; the permutation sits
+// in the per-lane global source address, which is free.
+// Out-of-range rows, conv padding taps and the K tail read a 16-byte zero page.
+#define G_BM 128
+#define G_BK 32
+#define G_STAGES 4
 
-__device__ __forceinline__ int lds_off(int row, int chunk) {   // in bf16 elements
-    return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
-}
+__device__ __attribute__((aligned(16))) unsigned int avsr_zero_page[4] = {0u, 0u, 0u, 0u};
 
-template <bool CONV, typename OutT>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][BM * BK];
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BN_, bool CONV, typename OutT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
+    constexpr int APIECES = G_BM / 16, BPIECES = BN_ / 16;
+    constexpr int STAGE_BYTES = (APIECES + BPIECES) * 1024;
+    constexpr int NJ = BN_ / 32;            // 16-column sub-tiles per wave
+    constexpr int NBL = BPIECES / 4;        // B pieces each wave loads per K-step
+    constexpr int LPT = 2 + NBL;            // DMA instructions per wave per K-step
+    __shared__ __attribute__((aligned(16))) char lds[G_STAGES * STAGE_BYTES];
+
     int tm, tn;
     tile_coords(p, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * G_BM, n0 = tn * BN_;
     const int bz = blockIdx.z;
     const bf16_t* A = (const bf16_t*)p.A + (long)bz * p.sA;
     const bf16_t* B = (const bf16_t*)p.B + (long)bz * p.sB;
     const long cbase = (long)bz * p.sC;
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int lc = t & 7, lr = t >> 3;
+    const int koff = (lane >> 4) * 8;       // this lane's k offset inside a K-step
 
-    f32x4 acc[4][4];
+    // ---- per-lane DMA sources -------------------------------------------------
+    // Address selection is pure integer arithmetic (zero + ((real - zero) & mask)): a ?: on the
+    // pointer lets the compiler branch around the DMA, and every wave must issue exactly LPT DMA
+    // instructions per step for the counted wait to mean anything.
+    const uintptr_t zaddr = (uintptr_t)avsr_zero_page;
+    uintptr_t baseA[2];
+    long stepA[2];
+    ConvRow crow[2];
+    int kh = 0, kw = 0, cc = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + (2 * wave + i) * 16 + (lane & 15);
+        if constexpr (CONV) { crow[i] = conv_row(p, m); baseA[i] = 0; stepA[i] = 0; }
+        else {
+            const long live = -(long)(m < p.M);
+            baseA[i] = zaddr + (((uintptr_t)(A + (long)m * p.lda + koff) - zaddr) & (uintptr_t)live);
+            stepA[i] = (long)(G_BK * sizeof(bf16_t)) & live;
+        }
+    }
+    if constexpr (CONV) conv_col(p, koff, kh, kw, cc);
+    uintptr_t baseB[NBL];
+    long stepB[NBL];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+        const int n = n0 + (NBL * wave + i) * 16 + (lane & 15);
+        const long live = -(long)(n < p.N);
+        baseB[i] = zaddr + (((uintptr_t)(B + (long)n * p.ldb + koff) - zaddr) & (uintptr_t)live);
+        stepB[i] = (long)(G_BK * sizeof(bf16_t)) & live;
+    }
+    const int nk = (p.K + G_BK - 1) / G_BK;
+
+    auto issue = [&](int kt) {              // DMA the operands of K-step kt into stage kt % 4
+        char* st = lds + (kt & (G_STAGES - 1)) * STAGE_BYTES;
+        const int kk = kt * G_BK + koff;
+        const uintptr_t kin = (uintptr_t)(-(long)(kk < p.K));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uintptr_t a;
+            if constexpr (CONV) {
+                const int ih = crow[i].ih0 + kh, iw = crow[i].iw0 + kw;
+                const bool ok = crow[i].ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                const uintptr_t real = (uintptr_t)(A + ((long)(crow[i].base + ih * p.W + iw)) * p.Cc + cc);
+                a = zaddr + ((real - zaddr) & kin & (uintptr_t)(-(long)ok));
+            } else a = zaddr + ((baseA[i] + (uintptr_t)(kt * stepA[i]) - zaddr) & kin);
+            __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (2 * wave + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NBL; ++i) {
+            const uintptr_t a = zaddr + ((baseB[i] + (uintptr_t)(kt * stepB[i]) - zaddr) & kin);
+            __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (APIECES + NBL * wave + i) * 1024), 16, 0, 0);
+        }
+        if constexpr (CONV) {               // advance the (tap, channel) cursor by one K-step
+            cc += G_BK;
+            while (cc >= p.Cc) { cc -= p.Cc; if (++kw == p.KW) { kw = 0; ++kh; } }
+        }
+    };
+
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    bf16x8 ra[4], rb[4];
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int nk = (p.K + BK - 1) / BK;
-
-    ConvRow crow[4];
-    if constexpr (CONV) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) crow[i] = conv_row(p, m0 + lr + 32 * i);
-    }
-    auto load_tile = [&](int kt) {
-        const int kk = kt * BK + lc * 8;
-        const bool kin = kk < p.K;
-        int kh = 0, kw = 0, cc = 0;
-        if constexpr (CONV) conv_col(p, kin ? kk : 0, kh, kw, cc);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + lr + 32 * i;
-            bool ok = kin && m < p.M;
-            const bf16_t* src;
-            if constexpr (CONV) src = conv_src<bf16_t>(p, A, crow[i], kh, kw, cc, ok);
-            else src = A + (long)m * p.lda + kk;
-            ra[i] = ok ? *(const bf16x8*)src : zero8;
-            const int n = n0 + lr + 32 * i;
-            const bool okb = kin && n < p.N;
-            rb[i] = okb ? *(const bf16x8*)(B + (long)n * p.ldb + kk) : zero8;
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = lr + 32 * i;
-            *(bf16x8*)&lds[buf][0][lds_off(r, lc)] = ra[i];
-            *(bf16x8*)&lds[buf][1][lds_off(r, lc)] = rb[i];
-        }
-    };
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    issue(0); issue(1); issue(2);           // steps past nk read the zero page: the wait count stays constant
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const bf16_t* As = lds[buf][0];
-        const bf16_t* Bs = lds[buf][1];
+        if constexpr (LPT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // every wave's pieces of step kt have landed; step kt-1 is fully read
+        issue(kt + 3);                      // refills the stage step kt-1 used
+        const char* st = lds + (kt & (G_STAGES - 1)) * STAGE_BYTES;
+        bf16x8 xf[4], wf[NJ];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 xf[4], wf[4];
-            const int ch = ks * 4 + (lane >> 4);
+        for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(st + (wm * 4 + i) * 1024 + lane * 16);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wm * 64 + i * 16 + (lane & 15);
-                xf[i] = *(const bf16x8*)&As[lds_off(row, ch)];
-            }
+        for (int j = 0; j < NJ; ++j) wf[j] = *(const bf16x8*)(st + (APIECES + wn * NJ + j) * 1024 + lane * 16);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wn * 64 + j * 16 + (lane & 15);
-                wf[j] = *(const bf16x8*)&Bs[lds_off(row, ch)];
-            }
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
     }
-
-    const float g = p.gate ? tanhf(*p.gate) : 1.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int nb = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-            f32x4 pre;
-            epilogue_quad<OutT>(p, acc[i][j], m, nb, g, cbase, pre);
-            if (m < p.M) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { s[r] += pre[r]; s2[r] += pre[r] * pre[r]; }
-            }
-        }
-        if (p.csum) stats_quad(p, s, s2, nb, lane);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-page steps before the LDS is reused
+    epilogue_tile<BN_, OutT>(p, acc, lds, m0, n0, tm, cbase, lane, wave);
 }
 
 // ----------------------------------------------------------------- f32 ----
@@ -340,12 +463,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
                 for (int r = 0; r < 4; ++r) { s[r] += pre[r]; s2[r] += pre[r] * pre[r]; }
             }
         }
-        if (p.csum) stats_quad(p, s, s2, nb, lane);
+        if (p.csum) stats_quad(p, s, s2, nb, lane, tm * 2 + wm);
     }
 }
 
 // ---------------------------------------------------------------- host ----
 static bool aligned_to(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+extern "C" int64_t avsr_gemm_stats_parts(int in_dtype, int64_t M) {
+    return in_dtype == AVSR_BF16 ? (M + G_BM - 1) / G_BM : 2 * ((M + FM - 1) / FM);
+}
 
 extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     if (!g || !g->A || !g->B || !g->C) return AVSR_EINVAL;
@@ -380,11 +507,12 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     p.H = g->conv.H; p.W = g->conv.W; p.Cc = g->conv.C; p.KH = g->conv.KH; p.KW = g->conv.KW;
     p.stride = g->conv.stride; p.pad_h = g->conv.pad_h; p.pad_w = g->conv.pad_w; p.OH = g->conv.OH; p.OW = g->conv.OW;
     const size_t osz = g->out_dtype == AVSR_BF16 ? 2 : 4;
-    const size_t vbytes = 4 * osz;
-    p.vec_ok = (g->ldc % 4 == 0) && aligned_to(g->C, vbytes) && ((g->strideC * osz) % vbytes == 0) &&
-               (!g->residual || ((g->ldr % 4 == 0) && aligned_to(g->residual, vbytes)));
-    if (g->residual && g->batch > 1) return AVSR_EUNSUPPORTED;
-    const int tmS = bf ? BM : FM, tnS = bf ? BN : FN;
+    // vector path: every row start of C (and of the residual) 16-byte aligned
+    p.vec_ok = ((g->ldc * osz) % 16 == 0) && aligned_to(g->C, 16) && ((g->strideC * osz) % 16 == 0) &&
+               (!g->residual || (((g->ldr * osz) % 16 == 0) && aligned_to(g->residual, 16)));
+    if ((g->residual || g->col_sum) && g->batch > 1) return AVSR_EUNSUPPORTED;
+    const int bn = (bf && g->N <= 64) ? 64 : 128;
+    const int tmS = bf ? G_BM : FM, tnS = bf ? bn : FN;
     p.tiles_m = (p.M + tmS - 1) / tmS;
     p.tiles_n = (p.N + tnS - 1) / tnS;
     const long ntiles = (long)p.tiles_m * p.tiles_n;
@@ -393,13 +521,20 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     hipStream_t s = (hipStream_t)stream;
     const bool of = g->out_dtype == AVSR_F32;
 #define LAUNCH(K, CV, OT) hipLaunchKernelGGL((K<CV, OT>), grid, block, 0, s, p)
+#define LAUNCHB(BNV, CV, OT) hipLaunchKernelGGL((gemm_bf16_kernel<BNV, CV, OT>), grid, block, 0, s, p)
     if (bf) {
-        if (conv) { if (of) LAUNCH(gemm_bf16_kernel, true, float); else LAUNCH(gemm_bf16_kernel, true, bf16_t); }
-        else      { if (of) LAUNCH(gemm_bf16_kernel, false, float); else LAUNCH(gemm_bf16_kernel, false, bf16_t); }
+        if (bn == 64) {
+            if (conv) { if (of) LAUNCHB(64, true, float); else LAUNCHB(64, true, bf16_t); }
+            else      { if (of) LAUNCHB(64, false, float); else LAUNCHB(64, false, bf16_t); }
+        } else {
+            if (conv) { if (of) LAUNCHB(128, true, float); else LAUNCHB(128, true, bf16_t); }
+            else      { if (of) LAUNCHB(128, false, float); else LAUNCHB(128, false, bf16_t); }
+        }
     } else {
         if (conv) { if (of) LAUNCH(gemm_f32_kernel, true, float); else LAUNCH(gemm_f32_kernel, true, bf16_t); }
         else      { if (of) LAUNCH(gemm_f32_kernel, false, float); else LAUNCH(gemm_f32_kernel, false, bf16_t); }
     }
 #undef LAUNCH
+#undef LAUNCHB
     return avsr_launch_status();
 }

@@ -183,17 +183,45 @@ extern "C" int avsr_layernorm_bwd(avsr_stream_t stream, int x_dtype, int g_dtype
 }
 
 // ------------------------------------------------------------ batch norm ---
-// Turn per-channel sums into the affine (scale, shift) the next kernel applies,
-// and update the running statistics the way nn.BatchNorm does in training mode
-// (momentum update with the UNBIASED variance).
-__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, float count,
-                                   const float* __restrict__ weight, const float* __restrict__ bias,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ scale, float* __restrict__ shift, int C, float eps, float momentum) {
+// Per-channel statistics arrive as [nparts, C] slabs of partial sums (one row per
+// producing workgroup: plain stores, fixed summation order, no atomics).
+#define BN_RED_PARTS 32
+
+// Fold nparts rows into BN_RED_PARTS rows: block (x = 64-channel group, y = output row s)
+// sums rows s, s+32, s+64, ... with its 4 waves and combines them through LDS.
+__global__ __launch_bounds__(256) void bn_reduce_parts_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq,
+                                                              int nparts, int C, float* __restrict__ ws) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, s = blockIdx.y;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int p = s + BN_RED_PARTS * w; p < nparts; p += BN_RED_PARTS * 4) {
+            a += sum[(long)p * C + c];
+            b += sumsq[(long)p * C + c];
+        }
+    red[0][w][lane] = a; red[1][w][lane] = b;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        ws[((long)s * 2 + 0) * C + c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+        ws[((long)s * 2 + 1) * C + c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    }
+}
+
+// Turn the partial sums into the affine (scale, shift) the next kernel applies, and update
+// the running statistics the way nn.BatchNorm does in training mode (momentum update with
+// the UNBIASED variance).  sum row r / sumsq row r live at sum + r*row_stride.
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, int nparts,
+                                   long row_stride, float count, const float* __restrict__ weight,
+                                   const float* __restrict__ bias, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift,
+                                   int C, float eps, float momentum) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float mean = sum[c] / count;
-    float var = sumsq[c] / count - mean * mean;
+    float s = 0.f, q = 0.f;
+    for (int p = 0; p < nparts; ++p) { s += sum[(long)p * row_stride + c]; q += sumsq[(long)p * row_stride + c]; }
+    const float mean = s / count;
+    float var = q / count - mean * mean;
     var = fmaxf(var, 0.f);
     const float sc = weight[c] * rsqrtf(var + eps);
     scale[c] = sc;
@@ -241,12 +269,24 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* __restrict__ x,
     }
 }
 
-extern "C" int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq, double count,
+extern "C" int64_t avsr_bn_finalize_workspace_floats(int64_t C) { return (int64_t)BN_RED_PARTS * 2 * C; }
+
+extern "C" int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq, int64_t nparts, double count,
                                 const float* weight, const float* bias, float* running_mean, float* running_var,
-                                float* scale, float* shift, int64_t C, float eps, float momentum) {
-    if (!sum || !sumsq || !weight || !bias || !scale || !shift || C <= 0 || count <= 0) return AVSR_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sum, sumsq,
-                       (float)count, weight, bias, running_mean, running_var, scale, shift, (int)C, eps, momentum);
+                                float* scale, float* shift, int64_t C, float eps, float momentum, float* ws) {
+    if (!sum || !sumsq || !weight || !bias || !scale || !shift || C <= 0 || count <= 0 || nparts <= 0) return AVSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 fgrid((unsigned)((C + 255) / 256)), fblock(256);
+    if (nparts > BN_RED_PARTS) {
+        if (!ws) return AVSR_EINVAL;
+        hipLaunchKernelGGL(bn_reduce_parts_kernel, dim3((unsigned)((C + 63) / 64), BN_RED_PARTS), dim3(256), 0, s, sum, sumsq,
+                           (int)nparts, (int)C, ws);
+        hipLaunchKernelGGL(bn_finalize_kernel, fgrid, fblock, 0, s, ws, ws + C, BN_RED_PARTS, (long)(2 * C), (float)count,
+                           weight, bias, running_mean, running_var, scale, shift, (int)C, eps, momentum);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_kernel, fgrid, fblock, 0, s, sum, sumsq, (int)nparts, (long)C, (float)count, weight,
+                           bias, running_mean, running_var, scale, shift, (int)C, eps, momentum);
+    }
     return avsr_launch_status();
 }
 

@@ -12,78 +12,92 @@
 
 // video: [B, T, 3, H, W] fp32 (the layout the reference's dataloader emits,
 // datamodule/data_module.py:142-152).  Output NHWC [B*T, OH, OW, 64].
-// One thread = one output pixel, all 64 channels; weights sit in LDS as
-// w[tap][cout] so every lane reads the same address (broadcast).
+// Block = 4 waves, 256 output pixels of one frame in 4 rounds of 64; wave w
+// computes channels 16w..16w+15 of each round's pixels, so a lane keeps 16
+// accumulators and every weight read is a wave-uniform LDS broadcast; the four
+// waves re-read the same input taps through L1.  `wpacked` is the weight
+// transposed to [tap][cout] (tap = ((ci*5+kt)*3+kh)*3+kw) so staging is a copy.
 // scale/shift != NULL: y = relu(conv*scale + shift) (eval-mode BN folded);
-// else the raw convolution is stored and per-channel sum / sum-of-squares are
-// accumulated for the batch statistics.
+// else the raw convolution is stored and per-channel sum / sum-of-squares of this
+// block go to row (frame*gridDim.x + blockIdx.x) of the [parts, 64] slabs.
+#define ST_CPW 16   // channels per wave
+#define ST_ROUNDS 4
 template <typename TO>
-__global__ __launch_bounds__(256) void stem3d_kernel(const float* __restrict__ video, const float* __restrict__ weight,
+__global__ __launch_bounds__(256) void stem3d_kernel(const float* __restrict__ video, const float* __restrict__ wpacked,
                                                      TO* __restrict__ out, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, float* __restrict__ csum,
                                                      float* __restrict__ csq, int T, int H, int W, int OH, int OW) {
     __shared__ __attribute__((aligned(16))) float ws[ST_TAPS * ST_CO];
-    for (int i = threadIdx.x; i < ST_TAPS * ST_CO; i += 256) {
-        const int tap = i / ST_CO, co = i - tap * ST_CO;
-        ws[i] = weight[co * ST_TAPS + tap];       // torch layout [co][ci][kt][kh][kw] = [co][tap]
-    }
+    for (int i = threadIdx.x; i < ST_TAPS * ST_CO / 4; i += 256) ((f32x4*)ws)[i] = ((const f32x4*)wpacked)[i];
     __syncthreads();
     const int frame = blockIdx.y;                  // b*T + t
     const int b = frame / T, t = frame - b * T;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    const bool live = pix < OH * OW;
-    const int oh = live ? pix / OW : 0, ow = live ? pix - oh * OW : 0;
-    float acc[ST_CO];
-#pragma unroll
-    for (int c = 0; c < ST_CO; ++c) acc[c] = 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = wave * ST_CPW;
     const long fsz = (long)3 * H * W;
-    for (int kt = 0; kt < ST_KT; ++kt) {
-        const int tt = t + kt - 2;
-        if (tt < 0 || tt >= T) continue;           // uniform over the block
-        const float* fp = video + ((long)b * T + tt) * fsz;
+    float st1[ST_CPW], st2[ST_CPW];
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci)
+    for (int c = 0; c < ST_CPW; ++c) { st1[c] = 0.f; st2[c] = 0.f; }
+    for (int rd = 0; rd < ST_ROUNDS; ++rd) {
+        const int pix = (blockIdx.x * ST_ROUNDS + rd) * 64 + lane;
+        const bool live = pix < OH * OW;
+        const int oh = live ? pix / OW : 0, ow = live ? pix - oh * OW : 0;
+        float acc[ST_CPW];
 #pragma unroll
-            for (int kh = 0; kh < ST_KH; ++kh)
+        for (int c = 0; c < ST_CPW; ++c) acc[c] = 0.f;
+        for (int kt = 0; kt < ST_KT; ++kt) {
+            const int tt = t + kt - 2;
+            if (tt < 0 || tt >= T) continue;           // uniform over the block
+            const float* fp = video + ((long)b * T + tt) * fsz;
+#pragma unroll 1
+            for (int ci = 0; ci < 3; ++ci) {
+#pragma unroll 1
+                for (int kh = 0; kh < ST_KH; ++kh) {
+                    const int ih = oh * 2 - 3 + kh;
+                    const bool rok = live && ih >= 0 && ih < H;
+                    const float* rp = fp + ((long)ci * H + (rok ? ih : 0)) * W;
+                    const int tap0 = ((ci * ST_KT + kt) * ST_KH + kh) * ST_KW;
 #pragma unroll
-                for (int kw = 0; kw < ST_KW; ++kw) {
-                    const int ih = oh * 2 - 3 + kh, iw = ow * 2 - 3 + kw;
-                    float x = 0.f;
-                    if (live && ih >= 0 && ih < H && iw >= 0 && iw < W) x = fp[((long)ci * H + ih) * W + iw];
-                    const int tap = ((ci * ST_KT + kt) * ST_KH + kh) * ST_KW + kw;
-                    const f32x4* wp = (const f32x4*)&ws[tap * ST_CO];
+                    for (int kw = 0; kw < ST_KW; ++kw) {
+                        const int iw = ow * 2 - 3 + kw;
+                        const float x = (rok && iw >= 0 && iw < W) ? rp[iw] : 0.f;
+                        const f32x4* wp = (const f32x4*)&ws[(tap0 + kw) * ST_CO + c0];
 #pragma unroll
-                    for (int c4 = 0; c4 < ST_CO / 4; ++c4) {
-                        const f32x4 w = wp[c4];
-                        acc[c4 * 4 + 0] = fmaf(x, w[0], acc[c4 * 4 + 0]);
-                        acc[c4 * 4 + 1] = fmaf(x, w[1], acc[c4 * 4 + 1]);
-                        acc[c4 * 4 + 2] = fmaf(x, w[2], acc[c4 * 4 + 2]);
-                        acc[c4 * 4 + 3] = fmaf(x, w[3], acc[c4 * 4 + 3]);
+                        for (int c4 = 0; c4 < ST_CPW / 4; ++c4) {
+                            const f32x4 w = wp[c4];
+                            acc[c4 * 4 + 0] = fmaf(x, w[0], acc[c4 * 4 + 0]);
+                            acc[c4 * 4 + 1] = fmaf(x, w[1], acc[c4 * 4 + 1]);
+                            acc[c4 * 4 + 2] = fmaf(x, w[2], acc[c4 * 4 + 2]);
+                            acc[c4 * 4 + 3] = fmaf(x, w[3], acc[c4 * 4 + 3]);
+                        }
                     }
                 }
+            }
+        }
+        if (!live) continue;
+#pragma unroll
+        for (int c = 0; c < ST_CPW; ++c) { st1[c] += acc[c]; st2[c] += acc[c] * acc[c]; }
+        TO* op = out + ((long)frame * OH * OW + pix) * ST_CO + c0;
+#pragma unroll
+        for (int c4 = 0; c4 < ST_CPW / 4; ++c4) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[c4 * 4 + e];
+                if (scale) x = fmaxf(x * scale[c0 + c4 * 4 + e] + shift[c0 + c4 * 4 + e], 0.f);
+                v[e] = x;
+            }
+            if constexpr (sizeof(TO) == 4) *(f32x4*)(op + c4 * 4) = (f32x4){v[0], v[1], v[2], v[3]};
+            else *(bf16x4*)(op + c4 * 4) = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        }
     }
     if (csum) {
-        const int lane = threadIdx.x & 63;
+        const long part = (long)frame * gridDim.x + blockIdx.x;
 #pragma unroll
-        for (int c = 0; c < ST_CO; ++c) {
-            const float v = live ? acc[c] : 0.f;
-            const float s = wave_sum(v), s2 = wave_sum(v * v);
-            if (lane == 0) { atomicAdd(csum + c, s); atomicAdd(csq + c, s2); }
+        for (int c = 0; c < ST_CPW; ++c) {
+            const float s = wave_sum(st1[c]), s2 = wave_sum(st2[c]);
+            if (lane == 0) { csum[part * ST_CO + c0 + c] = s; csq[part * ST_CO + c0 + c] = s2; }
         }
-    }
-    if (!live) return;
-    TO* op = out + ((long)frame * OH * OW + pix) * ST_CO;
-#pragma unroll
-    for (int c4 = 0; c4 < ST_CO / 4; ++c4) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = acc[c4 * 4 + e];
-            if (scale) x = fmaxf(x * scale[c4 * 4 + e] + shift[c4 * 4 + e], 0.f);
-            v[e] = x;
-        }
-        if constexpr (sizeof(TO) == 4) *(f32x4*)(op + c4 * 4) = (f32x4){v[0], v[1], v[2], v[3]};
-        else *(bf16x4*)(op + c4 * 4) = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
     }
 }
 
@@ -145,22 +159,29 @@ __global__ __launch_bounds__(256) void avgpool_mask_kernel(const T* __restrict__
     }
 }
 
-extern "C" int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float* video, const float* weight, void* out,
-                               const float* scale, const float* shift, float* col_sum, float* col_sumsq, int64_t B,
-                               int64_t T, int64_t H, int64_t W) {
-    if (!video || !weight || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0) return AVSR_EINVAL;
+// number of rows of the [parts, 64] statistics slabs avsr_stem3d_fwd fills
+extern "C" int64_t avsr_stem3d_stats_parts(int64_t B, int64_t T, int64_t H, int64_t W) {
+    const int64_t OH = (H + 6 - 3) / 2 + 1, OW = (W + 6 - 3) / 2 + 1;
+    return B * T * ((OH * OW + 64 * ST_ROUNDS - 1) / (64 * ST_ROUNDS));
+}
+
+extern "C" int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float* video, const float* weight_packed,
+                               void* out, const float* scale, const float* shift, float* col_sum, float* col_sumsq,
+                               int64_t B, int64_t T, int64_t H, int64_t W) {
+    if (!video || !weight_packed || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0) return AVSR_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return AVSR_EINVAL;
     if ((col_sum == nullptr) != (col_sumsq == nullptr)) return AVSR_EINVAL;
+    if ((uintptr_t)weight_packed % 16) return AVSR_EUNSUPPORTED;
     const int OH = (int)((H + 6 - 3) / 2 + 1), OW = (int)((W + 6 - 3) / 2 + 1);
     if (B * T > 65535) return AVSR_EUNSUPPORTED;
-    dim3 grid((unsigned)((OH * OW + 255) / 256), (unsigned)(B * T));
+    dim3 grid((unsigned)((OH * OW + 64 * ST_ROUNDS - 1) / (64 * ST_ROUNDS)), (unsigned)(B * T));
     hipStream_t s = (hipStream_t)stream;
     if (out_dtype == AVSR_F32)
-        hipLaunchKernelGGL(stem3d_kernel<float>, grid, dim3(256), 0, s, video, weight, (float*)out, scale, shift, col_sum,
-                           col_sumsq, (int)T, (int)H, (int)W, OH, OW);
+        hipLaunchKernelGGL(stem3d_kernel<float>, grid, dim3(256), 0, s, video, weight_packed, (float*)out, scale, shift,
+                           col_sum, col_sumsq, (int)T, (int)H, (int)W, OH, OW);
     else if (out_dtype == AVSR_BF16)
-        hipLaunchKernelGGL(stem3d_kernel<bf16_t>, grid, dim3(256), 0, s, video, weight, (bf16_t*)out, scale, shift, col_sum,
-                           col_sumsq, (int)T, (int)H, (int)W, OH, OW);
+        hipLaunchKernelGGL(stem3d_kernel<bf16_t>, grid, dim3(256), 0, s, video, weight_packed, (bf16_t*)out, scale, shift,
+                           col_sum, col_sumsq, (int)T, (int)H, (int)W, OH, OW);
     else return AVSR_EINVAL;
     return avsr_launch_status();
 }

@@ -8,9 +8,8 @@ Frozen in the reference (models/av_net.py:45-46): forward only.  Activations are
 NHWC; every convolution of the trunk is an implicit GEMM.  BatchNorm follows
 ``self.training`` like the reference does: eval = running statistics folded
 into the GEMM epilogue; train = batch statistics accumulated in the epilogue,
-one finalize + one apply kernel per BN, running statistics updated in place
-(the pre-normalisation tensor stays fp32 so the batch statistics and the
-normalised values see the same numbers).
+one finalize + one in-place apply kernel per BN, running statistics updated in
+place (the statistics come from the fp32 accumulators, before rounding).
 """
 import math
 
@@ -87,7 +86,7 @@ class MoCoVisualFrontend(nn.Module):
             w = conv.weight.detach()
             return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
 
-        pk = {"stem_w": self.frontend3D[0].weight.detach().float().contiguous(), "blocks": [], "fold": {}}
+        pk = {"stem_w": ops.stem_pack_weight(self.frontend3D[0].weight), "blocks": [], "fold": {}}
         if not self.training:      # eval: fold every BN's running statistics once per weight version
             for m in self.modules():
                 if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
@@ -114,13 +113,13 @@ class MoCoVisualFrontend(nn.Module):
                 act, res2d = (ops.ACT_RELU if relu else ops.ACT_NONE), None
             return ops.conv_nhwc(x, w, k, k, stride, pad, scale=sc, bias=sh, act=act, residual=res2d)
         C = w.shape[0]
-        stats = torch.zeros((2, C), dtype=torch.float32, device=x.device)
-        raw = ops.conv_nhwc(x, w, k, k, stride, pad, col_stats=(stats[0], stats[1]), out_dtype=torch.float32)
-        sc = torch.empty(C, dtype=torch.float32, device=x.device)
-        sh = torch.empty(C, dtype=torch.float32, device=x.device)
-        ops.bn_finalize(stats[0], stats[1], raw.numel() // C, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
-                        bn.running_var, sc, sh, bn.eps, bn.momentum)
-        return ops.bn_apply(raw, sc, sh, residual=residual, relu=relu, out_dtype=x.dtype)
+        rows = ops.conv_out_rows(x, k, k, stride, pad)
+        stats = ops.gemm_stats_slabs(rows, C, x.dtype, x.device)
+        raw = ops.conv_nhwc(x, w, k, k, stride, pad, col_stats=(stats[0], stats[1]))
+        aff = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        ops.bn_finalize(stats[0], stats[1], rows, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                        bn.running_var, aff[0], aff[1], bn.eps, bn.momentum)
+        return ops.bn_apply(raw, aff[0], aff[1], residual=residual, relu=relu, out=raw)
 
     @torch.no_grad()
     def run_stem(self, video):
@@ -131,13 +130,12 @@ class MoCoVisualFrontend(nn.Module):
         if not self.training:
             sc, sh = self._fold(bn0)
             return ops.maxpool3x3s2(ops.stem3d_fwd(video, pk["stem_w"], dtype, scale=sc, shift=sh))
-        stats = torch.zeros((2, 64), dtype=torch.float32, device=video.device)
-        raw = ops.stem3d_fwd(video, pk["stem_w"], torch.float32, col_stats=(stats[0], stats[1]))
-        sc = torch.empty(64, dtype=torch.float32, device=video.device)
-        sh = torch.empty(64, dtype=torch.float32, device=video.device)
+        stats = ops.stem_stats_slabs(video)
+        raw = ops.stem3d_fwd(video, pk["stem_w"], dtype, col_stats=(stats[0], stats[1]))
+        aff = torch.empty((2, 64), dtype=torch.float32, device=video.device)
         ops.bn_finalize(stats[0], stats[1], raw.numel() // 64, bn0.weight.detach(), bn0.bias.detach(),
-                        bn0.running_mean, bn0.running_var, sc, sh, bn0.eps, bn0.momentum)
-        return ops.maxpool3x3s2(raw, scale=sc, shift=sh, out_dtype=dtype)
+                        bn0.running_mean, bn0.running_var, aff[0], aff[1], bn0.eps, bn0.momentum)
+        return ops.maxpool3x3s2(raw, scale=aff[0], shift=aff[1])
 
     @torch.no_grad()
     def run_block(self, index, y):

@@ -101,6 +101,19 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
     return out
 
 
+def gemm_stats_slabs(M, N, dtype, device):
+    """Zero-free allocation of the [2, parts, N] partial-sum slabs a gemm_nt / conv_nhwc launch with
+    M output rows fills completely (pass ``col_stats=(s[0], s[1])``)."""
+    parts = _lib.load().avsr_gemm_stats_parts(_DT[dtype], M)
+    return torch.empty((2, parts, N), dtype=torch.float32, device=device)
+
+
+def conv_out_rows(x, KH, KW, stride, pad):
+    n, H, W, _ = x.shape
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    return n * ((H + 2 * ph - KH) // stride + 1) * ((W + 2 * pw - KW) // stride + 1)
+
+
 def conv_nhwc(x, w, KH, KW, stride, pad, **kw):
     """x: [N,H,W,C] contiguous; w: [Cout, KH*KW*C] -> [N,OH,OW,Cout].  ``pad`` is an int or (pad_h, pad_w)."""
     n, H, W, C = x.shape
@@ -180,15 +193,28 @@ def attn_bwd(q, k, v, o, do, lse, H, *, key_mask=None, scale=1.0, p_drop=0.0, se
     return dq, dk, dv
 
 
+def stem_pack_weight(weight):
+    """[64,3,5,3,3] conv weight -> [135 taps, 64] fp32, the layout the stem kernel stages."""
+    if tuple(weight.shape) != (64, 3, 5, 3, 3):
+        raise ValueError("stem weight must be [64,3,5,3,3]")
+    return weight.detach().float().reshape(64, 135).t().contiguous()
+
+
+def stem_stats_slabs(video):
+    B, T, _, H, W = video.shape
+    parts = _lib.load().avsr_stem3d_stats_parts(B, T, H, W)
+    return torch.empty((2, parts, 64), dtype=torch.float32, device=video.device)
+
+
 def stem3d_fwd(video, weight, out_dtype, *, scale=None, shift=None, col_stats=None):
-    """video [B,T,3,H,W] fp32 contiguous -> NHWC [B*T,OH,OW,64]."""
+    """video [B,T,3,H,W] fp32 contiguous -> NHWC [B*T,OH,OW,64]; weight = stem_pack_weight(w)."""
     lib = _lib.load()
     _need_cuda(video, weight)
     if video.dtype != torch.float32 or not video.is_contiguous() or weight.dtype != torch.float32:
         raise ValueError("stem expects contiguous fp32 video and fp32 weight")
     B, T, C, H, W = video.shape
-    if C != 3 or tuple(weight.shape) != (64, 3, 5, 3, 3):
-        raise ValueError("stem shape mismatch")
+    if C != 3 or tuple(weight.shape) != (135, 64) or not weight.is_contiguous():
+        raise ValueError("stem shape mismatch (weight must be packed with stem_pack_weight)")
     OH, OW = (H + 6 - 3) // 2 + 1, (W + 6 - 3) // 2 + 1
     out = torch.empty((B * T, OH, OW, 64), dtype=out_dtype, device=video.device)
     cs = col_stats or (None, None)
@@ -218,10 +244,16 @@ def avgpool_mask(x, lens, B, T, out_dtype):
 
 
 def bn_finalize(col_sum, col_sumsq, count, weight, bias, running_mean, running_var, scale, shift, eps=1e-5, momentum=0.1):
+    """col_sum / col_sumsq: [parts, C] partial-sum slabs (or [C])."""
     lib = _lib.load()
-    check(lib.avsr_bn_finalize(_stream(), col_sum.data_ptr(), col_sumsq.data_ptr(), float(count), weight.data_ptr(),
+    C = weight.numel()
+    nparts = col_sum.numel() // C
+    ws = None
+    if nparts > 32:
+        ws = torch.empty(lib.avsr_bn_finalize_workspace_floats(C), dtype=torch.float32, device=weight.device)
+    check(lib.avsr_bn_finalize(_stream(), col_sum.data_ptr(), col_sumsq.data_ptr(), nparts, float(count), weight.data_ptr(),
                                bias.data_ptr(), _p(running_mean), _p(running_var), scale.data_ptr(), shift.data_ptr(),
-                               weight.numel(), eps, momentum), "avsr_bn_finalize")
+                               C, eps, momentum, _p(ws)), "avsr_bn_finalize")
 
 
 def bn_fold(weight, bias, running_mean, running_var, eps=1e-5):

@@ -66,9 +66,10 @@ def test_gemm_epilogue(dev, dtype):
     assert rel_err(out, ref) < tol(dtype)
     # periodic residual (positional table) + relu + column statistics
     table = torch.randn(37, N, generator=g)
-    cs = torch.zeros(2, N, device=dev)
+    cs = ops.gemm_stats_slabs(M, N, dtype, dev)
     out = ops.gemm_nt(a.to(dev, dtype), b.to(dev, dtype), out_dtype=torch.float32, bias=bias.to(dev), act=ops.ACT_RELU,
                       residual=table.to(dev), res_period=37, col_stats=(cs[0], cs[1]))
+    cs = cs.sum(1)
     pre = a @ b.T + bias
     ref = table[torch.arange(M) % 37] + F.relu(pre)
     assert rel_err(out, ref) < tol(dtype)
@@ -215,19 +216,20 @@ def test_stem_pool_bn(dev, odt):
     ref = F.max_pool3d(F.relu(F.batch_norm(conv, rm, rv, bw, bb, False)), (1, 3, 3), (1, 2, 2), (0, 1, 1))
     ref = ref.permute(0, 2, 3, 4, 1).reshape(B * T, ref.shape[3], ref.shape[4], 64)
     sc, sh = ops.bn_fold(bw.to(dev), bb.to(dev), rm.to(dev), rv.to(dev))
-    y = ops.stem3d_fwd(video.to(dev), w.to(dev), odt, scale=sc, shift=sh)
+    wp = ops.stem_pack_weight(w.to(dev))
+    y = ops.stem3d_fwd(video.to(dev), wp, odt, scale=sc, shift=sh)
     out = ops.maxpool3x3s2(y)
     assert out.shape == ref.shape and rel_err(out, ref) < tol(odt)
     # training mode: raw conv + batch statistics, affine+relu inside the pool
     rm2, rv2 = rm.clone(), rv.clone()
     ref_t = F.max_pool3d(F.relu(F.batch_norm(conv, rm2, rv2, bw, bb, True)), (1, 3, 3), (1, 2, 2), (0, 1, 1))
     ref_t = ref_t.permute(0, 2, 3, 4, 1).reshape(B * T, ref.shape[1], ref.shape[2], 64)
-    cs = torch.zeros(2, 64, device=dev)
-    raw = ops.stem3d_fwd(video.to(dev), w.to(dev), torch.float32, col_stats=(cs[0], cs[1]))
+    cs = ops.stem_stats_slabs(video.to(dev))
+    raw = ops.stem3d_fwd(video.to(dev), wp, odt, col_stats=(cs[0], cs[1]))
     rmd, rvd = rm.to(dev), rv.to(dev)
     sc2, sh2 = torch.empty(64, device=dev), torch.empty(64, device=dev)
     ops.bn_finalize(cs[0], cs[1], raw.numel() // 64, bw.to(dev), bb.to(dev), rmd, rvd, sc2, sh2)
-    out_t = ops.maxpool3x3s2(raw, scale=sc2, shift=sh2, out_dtype=odt)
+    out_t = ops.maxpool3x3s2(raw, scale=sc2, shift=sh2)
     assert rel_err(out_t, ref_t) < tol(odt) * 2
     assert rel_err(rmd, rm2) < 1e-3 and rel_err(rvd, rv2) < 1e-3
     # bn_apply with residual
