@@ -1,0 +1,137 @@
+"""CPU tests of the host-side logic: checkpoint key compatibility, the trainable-parameter set,
+the learning-rate schedule, and the data-parallel gradient reducer over gloo (world size 2)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from mocov2_whisper_flamingo_amd import AVNet, WhisperConfig
+from mocov2_whisper_flamingo_amd.dp import FlatTrainer, one_cycle_lr, trainable_parameters
+from tests.helpers import seed_module, synthetic_batch
+
+MICRO = WhisperConfig(d_model=128, encoder_layers=2, encoder_attention_heads=2, decoder_layers=1,
+                      decoder_attention_heads=2)
+
+
+def micro_model(seed=21):
+    m = AVNet("audiovisual", None, 96, (128, 2, 4, 3000, 512, 0.1), 503, whisper_config=MICRO, dtype=torch.float32)
+    return m, seed_module(m, seed)
+
+
+def test_state_dict_keys_match_reference_layout():
+    m, sd = micro_model()
+    keys = set(sd)
+    # models/av_net.py:22-63, gate_cross_attention.py:16-27,56-59, moco_visual_frontend.py:14-26, utils.py:18,34
+    for k in ["whisper_model.encoder.conv1.weight", "whisper_model.encoder.embed_positions.weight",
+              "whisper_model.encoder.layers.0.self_attn.k_proj.weight", "whisper_model.encoder.layers.1.fc2.bias",
+              "whisper_model.encoder.layer_norm.weight", "whisper_model.decoder.embed_tokens.weight",
+              "whisper_model.decoder.layers.0.encoder_attn.q_proj.weight", "audio_proj.weight", "audio_ln.bias",
+              "visual_model.frontend3D.0.weight", "visual_model.frontend3D.1.running_var",
+              "visual_model.frontend3D.1.num_batches_tracked", "visual_model.MoCoModel.layer1.0.downsample.0.weight",
+              "visual_model.MoCoModel.layer1.0.downsample.1.running_mean", "visual_model.MoCoModel.layer3.5.bn3.weight",
+              "visual_model.MoCoModel.layer4.2.conv3.weight", "video_proj.bias", "video_ln.weight",
+              "fusion_module.audio_proj.weight", "fusion_module.video_proj.bias", "fusion_module.ln_post.weight",
+              "fusion_module.layers.0.attn.in_proj_weight", "fusion_module.layers.0.attn.in_proj_bias",
+              "fusion_module.layers.1.attn.out_proj.weight", "fusion_module.layers.0.attn_ln.weight",
+              "fusion_module.layers.0.ff_ln.bias", "fusion_module.layers.0.attn_gate", "fusion_module.layers.1.ff_gate",
+              "fusion_module.layers.0.ff.0.weight", "fusion_module.layers.1.ff.2.bias", "fusion_scalar",
+              "pos_enc_audio.pe", "pos_enc_video.pe", "decoder.linear.weight", "decoder.linear.bias"]:
+        assert k in keys, k
+    assert "whisper_model.encoder.layers.0.self_attn.k_proj.bias" not in keys      # k_proj has no bias
+    assert sd["pos_enc_audio.pe"].shape == (1, 5000, 128)
+    assert sd["visual_model.frontend3D.0.weight"].shape == (64, 3, 5, 3, 3)
+    assert len(m.fusion_module.layers) == 2                                          # n_layers // 2
+    # resnet50 trunk parameter count (no stem conv/bn, no fc): 23,508,032 - 9,408 - 128 (+ nothing for fc=Identity)
+    n_trunk = sum(p.numel() for p in m.visual_model.MoCoModel.parameters())
+    assert n_trunk == 23508032 - 9408 - 128
+    # a Lightning checkpoint prefixes keys with "model."; stripping it loads cleanly
+    m2, _ = micro_model(seed=5)
+    m2.load_state_dict({k: v for k, v in sd.items()}, strict=True)
+
+
+def test_frozen_and_trainable_sets():
+    m, _ = micro_model()
+    names = [n for n, _ in trainable_parameters(m)]
+    assert all(not n.startswith(("whisper_model.", "visual_model.")) for n in names)
+    assert "fusion_scalar" not in names and "decoder.linear.weight" in names
+    assert all(not p.requires_grad for p in m.whisper_model.encoder.parameters())
+    assert all(not p.requires_grad for p in m.visual_model.parameters())
+    assert set(names) == {k for k in m.state_dict() if k.startswith(oracle.ref_avnet.TRAINABLE_PREFIXES)
+                          and not k.endswith(".pe")}
+
+
+def test_full_size_parameter_counts():
+    # the figures the gradient exchange is sized from: fusion 9,983,494; head 26,606,745; projections
+    from mocov2_whisper_flamingo_amd import Decoder, GatedCrossModalFusion
+    assert sum(p.numel() for p in GatedCrossModalFusion(512, 8, 3).parameters()) == 9983494
+    assert sum(p.numel() for p in Decoder(512, 51865).parameters()) == 26606745
+
+
+def test_one_cycle_matches_torch():
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=50, pct_start=0.1, div_factor=25.0,
+                                              final_div_factor=1e4, anneal_strategy="linear")
+    for i in range(50):
+        assert abs(opt.param_groups[0]["lr"] - one_cycle_lr(i, 50)) < 1e-12
+        opt.step()
+        if i < 49:
+            sch.step()
+
+
+def test_ops_refuse_cpu_tensors():
+    from mocov2_whisper_flamingo_amd import _lib
+    m, _ = micro_model()
+    b = synthetic_batch(B=1, Tv=2, H=32, W=32)
+    with pytest.raises(_lib.AvsrHipError):
+        m((b["audio"], b["audio_mask"], b["video"], b["video_mask"], b["video_lengths"]))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    m, sd = micro_model()
+    tr = FlatTrainer(m, bucket_mb=0.25, overlap=False)
+    full = synthetic_batch(B=2 * world, Tv=6, H=32, W=32, L=4, vocab=503, seed=3)
+    mine = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
+    _, _, _, _, grads, _ = oracle.training_step(sd, mine, 2, 2, masked_row="zero")
+    tr.zero_grad()
+    params = dict(m.named_parameters())
+    with torch.no_grad():
+        for k, g in grads.items():
+            params[k].grad.copy_(g)          # .grad is a view into the flat bucket buffer
+    tr.reduce_gradients()
+    if rank == 0:
+        _, _, _, _, ref, _ = oracle.training_step(sd, full, 2, 2, masked_row="zero")
+        worst = max(((params[k].grad - ref[k]).abs().max() / ref[k].abs().max().clamp_min(1e-6)).item() for k in ref)
+        q.put((worst, len(tr.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_gradient_mean_over_gloo_equals_full_batch():
+    """N-rank averaged gradients == single-rank gradients on the concatenated batch (eval-mode BN)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    worst, nb = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert nb > 1 and worst < 1e-4

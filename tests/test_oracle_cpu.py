@@ -1,0 +1,149 @@
+"""CPU tests (no GPU): the oracle against the committed golden vectors (captured from the reference's own
+classes and from the transformers classes it calls - tests/golden/make_goldens.py) and, live, against the
+transformers implementation installed in this image."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import ref_fusion, ref_logmel
+from tests.helpers import seeded_values
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _seeded_sd(module, seed):
+    sd = module.state_dict()
+    vals = seeded_values({k: (tuple(v.shape), v.dtype) for k, v in sd.items()}, seed)
+    out = {k: v.clone() for k, v in sd.items()}
+    out.update(vals)
+    return out
+
+
+def test_fusion_matches_reference_golden():
+    from mocov2_whisper_flamingo_amd import GatedCrossModalFusion
+    g = np.load(os.path.join(GOLD, "fusion.npz"))
+    d, H, N, B, T = 512, 8, 3, 2, 75
+    sd = _seeded_sd(GatedCrossModalFusion(d, H, N, dropout=0.1), 13)
+    gen = torch.Generator().manual_seed(2)
+    a = torch.randn(B, T, d, generator=gen).requires_grad_(True)
+    v = torch.randn(B, T, d, generator=gen).requires_grad_(True)
+    mask = torch.zeros(B, T, dtype=torch.bool)
+    mask[1, 40:] = True
+    dout = torch.randn(B, T, d, generator=gen)
+    leaf = {k: (t.clone().requires_grad_(True) if t.is_floating_point() else t) for k, t in sd.items()}
+    y = oracle.fusion_forward(leaf, "", a, v, H, mask)
+    y.backward(dout)
+    assert np.abs(y.detach().numpy() - g["y"]).max() < 2e-5
+    assert np.abs(a.grad.numpy() - g["da"]).max() < 2e-5
+    assert np.abs(v.grad.numpy() - g["dv"]).max() < 2e-5
+    for k, t in leaf.items():
+        if t.is_floating_point():
+            assert abs(t.grad.double().norm().item() - float(g["gnorm/" + k])) < 1e-4 * max(1.0, float(g["gnorm/" + k])), k
+            # a sum over a zero-mean matrix cancels: scale its tolerance by the gradient's norm
+            assert abs(t.grad.double().sum().item() - float(g["gsum/" + k])) < 1e-4 * max(1.0, float(g["gnorm/" + k])), k
+
+
+def test_head_pe_losses_match_reference_golden():
+    from mocov2_whisper_flamingo_amd import Decoder, LayerNorm
+    g = np.load(os.path.join(GOLD, "head_pe.npz"))
+    d, V, B, T, L = 128, 503, 2, 6, 4
+    pe = ref_fusion.positional_encoding_table(d)
+    assert np.abs(pe[0, :64].numpy() - g["pe_slice"]).max() < 1e-6
+    dec = _seeded_sd(Decoder(d, V), 31)
+    ln = _seeded_sd(LayerNorm(d), 32)
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(B, T, d, generator=gen)
+    h = ref_fusion.positional_encoding(ref_fusion.layer_norm_fp32(x, ln["weight"], ln["bias"]), pe)
+    logits = torch.nn.functional.linear(h, dec["linear.weight"], dec["linear.bias"])
+    assert np.abs(logits.numpy() - g["logits"]).max() < 1e-5
+    assert np.array_equal(logits.argmax(-1).numpy(), g["argmax"])
+    targets = torch.randint(1, V, (B, L), generator=gen)
+    ctc, ce = oracle.ctc_ce_loss(logits, targets, torch.full((B,), T), torch.full((B,), L))
+    assert abs(ctc.item() - float(g["ctc"])) < 1e-5 and abs(ce.item() - float(g["ce"])) < 1e-5
+
+
+def _whisper_case(name):
+    from mocov2_whisper_flamingo_amd import WhisperConfig, WhisperEncoder
+    D, Ly, H, B = {"micro": (128, 2, 2, 1), "tiny": (384, 4, 6, 2)}[name]
+    cfg = WhisperConfig(d_model=D, encoder_layers=Ly, encoder_attention_heads=H, with_decoder=False)
+    sd = _seeded_sd(WhisperEncoder(cfg), 7)
+    gen = torch.Generator().manual_seed(3)
+    return sd, torch.randn(B, 80, 3000, generator=gen), H, cfg
+
+
+def test_whisper_encoder_matches_transformers_golden():
+    g = np.load(os.path.join(GOLD, "whisper.npz"))
+    sd, mel, H, _ = _whisper_case("micro")
+    y = oracle.whisper_encoder(sd, "", mel, H)
+    assert np.abs(y.numpy() - g["micro/y"]).max() < 2e-4
+    sd, mel, H, _ = _whisper_case("tiny")
+    y = oracle.whisper_encoder(sd, "", mel, H)
+    assert np.abs(y[:, :8].numpy() - g["tiny/first"]).max() < 2e-4
+    assert np.abs(y[:, -8:].numpy() - g["tiny/last"]).max() < 2e-4
+    assert abs(y.double().abs().sum().item() - float(g["tiny/abssum"])) < 1e-5 * float(g["tiny/abssum"])
+    with pytest.raises(ValueError):
+        oracle.whisper_encoder(sd, "", mel[:, :, :1000], H)
+
+
+def test_whisper_encoder_matches_transformers_live():
+    transformers = pytest.importorskip("transformers")
+    sd, mel, H, cfg = _whisper_case("micro")
+    hf_cfg = transformers.WhisperConfig(d_model=cfg.d_model, encoder_layers=cfg.encoder_layers, encoder_attention_heads=H,
+                                        encoder_ffn_dim=4 * cfg.d_model, decoder_layers=1, decoder_attention_heads=H,
+                                        decoder_ffn_dim=4 * cfg.d_model, num_mel_bins=80, vocab_size=51865,
+                                        attn_implementation="eager")
+    enc = transformers.WhisperModel(hf_cfg).encoder.eval()
+    missing = enc.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        ref = enc(mel)[0]
+    assert (oracle.whisper_encoder(sd, "", mel, H) - ref).abs().max().item() < 2e-4
+
+
+def test_logmel_matches_feature_extractor():
+    g = np.load(os.path.join(GOLD, "logmel.npz"))
+    gen = torch.Generator().manual_seed(5)
+    wave = 0.1 * torch.randn(160000, generator=gen)
+    padded = torch.zeros(1, 480000)
+    padded[0, :160000] = wave
+    feats = oracle.whisper_logmel(padded)[0]
+    assert feats.shape == (80, 3000)
+    assert np.abs(feats[:, ::7].numpy() - g["feats_sub"]).max() < 2e-4
+    transformers = pytest.importorskip("transformers")
+    fe = transformers.WhisperFeatureExtractor()
+    live = fe(wave.numpy(), sampling_rate=16000, return_tensors="np")["input_features"][0]
+    assert np.abs(feats.numpy() - live).max() < 2e-4
+    assert np.abs(ref_logmel.mel_filters_slaney() - fe.mel_filters).max() < 1e-6
+
+
+def test_visual_restatement_self_consistent():
+    """PARITY UNPINNED (torchvision absent): checks structure only - output shape, frame masking, and that the
+    training-mode path moves the running statistics the way nn.BatchNorm2d does."""
+    from mocov2_whisper_flamingo_amd import MoCoVisualFrontend
+    m = MoCoVisualFrontend()
+    sd = _seeded_sd(m, 11)
+    gen = torch.Generator().manual_seed(1)
+    video = torch.randn(1, 3, 3, 32, 32, generator=gen)
+    y = oracle.visual_frontend(sd, "", video, torch.tensor([2]))
+    assert y.shape == (1, 3, 2048) and (y[0, 2] == 0).all() and y[0, :2].abs().sum() > 0
+    stats = {}
+    oracle.visual_frontend(sd, "", video, torch.tensor([3]), training=True, new_stats=stats)
+    bn = torch.nn.BatchNorm2d(64)
+    bn.load_state_dict({k.split(".")[-1]: v for k, v in sd.items() if k.startswith("MoCoModel.layer1.0.bn1.")})
+    assert int(stats["MoCoModel.layer1.0.bn1.num_batches_tracked"]) == 1
+    assert not torch.equal(stats["MoCoModel.layer1.0.bn1.running_mean"], sd["MoCoModel.layer1.0.bn1.running_mean"])
+
+
+def test_all_keys_masked_policy():
+    sd = {"w": None}
+    q = torch.randn(1, 3, 64)
+    kv = torch.randn(1, 4, 64)
+    in_w, in_b = torch.randn(192, 64) * 0.1, torch.zeros(192)
+    ow, ob = torch.randn(64, 64) * 0.1, torch.randn(64)
+    mask = torch.ones(1, 4, dtype=torch.bool)
+    nan = oracle.mha_forward(q, kv, in_w, in_b, ow, ob, 1, mask)            # torch's behaviour
+    zero = oracle.mha_forward(q, kv, in_w, in_b, ow, ob, 1, mask, masked_row="zero")
+    assert torch.isnan(nan).all()
+    assert torch.allclose(zero, ob.expand(1, 3, 64))
