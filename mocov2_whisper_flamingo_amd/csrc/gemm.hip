@@ -252,35 +252,56 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[4][BN
 }
 
 // ---------------------------------------------------------------- bf16 ----
-// 128 x BN x 32 tiles, 4 waves, v_mfma_f32_16x16x32_bf16.  Operand tiles go
-// global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction)
-// into a 4-stage ring; three K-steps of loads stay in flight across the raw
-// s_barrier behind a counted s_waitcnt vmcnt, so HBM/L2 latency is covered by
-// three compute phases plus the second resident workgroup of the CU.
+// 128 x BN x 64 tiles, 4 waves, v_mfma_f32_16x16x32_bf16.  Operand tiles go
+// global -> LDS directly (global_load_lds_dwordx4): one wave instruction moves
+// 8 rows x 128 B, i.e. whole cache lines, into a ring of G_NST stages; with more
+// than one stage the loads of the following K-steps stay in flight across the
+// raw s_barrier behind a counted s_waitcnt vmcnt.
 //
-// LDS image: one 1-KiB "piece" per 16-row sub-tile, laid out in FRAGMENT order:
-// byte 16*l of a piece holds (row l&15, k-chunk l>>4), exactly the 8 bf16 lane l
-// feeds to the MFMA.  The DMA writes lane-linear, the ds_read_b128 reads
-// lane-linear: both conflict-free, no swizzle arithmetic; the permutation sits
-// in the per-lane global source address, which is free.
+// LDS image: row-major [rows][128 B]; the 16-byte chunk c of row r sits at chunk
+// position c ^ ((r >> 1) & 7).  The DMA writes lane-linear, so the XOR is applied
+// to the per-lane SOURCE address (lane i of a piece fetches chunk (i&7) ^ swz of
+// row i>>3) and again on the ds_read_b128 side: conflict-free for the 16-row
+// fragment reads of the 16x16x32 MFMA.
 // Out-of-range rows, conv padding taps and the K tail read a 16-byte zero page.
 #define G_BM 128
-#define G_BK 32
-#define G_STAGES 4
+#define G_BK 64
+// Two instantiations, picked per launch by the number of tiles (measured, interleaved A/B on MI355X):
+//   NST = 1: one 32-KiB stage, two barriers per K-step, 4 workgroups per CU - latency is hidden by
+//            the other resident workgroups; fastest whenever the grid can fill the chip (about 500 tiles or more).
+//   NST = 2: double-buffered, 2 workgroups per CU - better when there are too few tiles for that.
+#ifndef G_NST_SWITCH_TILES
+#define G_NST_SWITCH_TILES 500
+#endif
 
 __device__ __attribute__((aligned(16))) unsigned int avsr_zero_page[4] = {0u, 0u, 0u, 0u};
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BN_, bool CONV, typename OutT>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
-    constexpr int APIECES = G_BM / 16, BPIECES = BN_ / 16;
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "unsupported wait count");
+}
+
+template <int BN_, int G_NST> constexpr int gemm_lds_bytes() {
+    constexpr int stage = (G_BM / 8 + BN_ / 8) * 1024;
+    constexpr int epi = (64 * (BN_ + 4) + 8 * BN_) * 4;
+    return G_NST * stage > epi ? G_NST * stage : epi;
+}
+
+template <int BN_, int G_NST, bool CONV, typename OutT>
+__global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(GemmP p) {
+    constexpr int APIECES = G_BM / 8, BPIECES = BN_ / 8;      // 1-KiB pieces (8 rows x 128 B)
     constexpr int STAGE_BYTES = (APIECES + BPIECES) * 1024;
     constexpr int NJ = BN_ / 32;            // 16-column sub-tiles per wave
-    constexpr int NBL = BPIECES / 4;        // B pieces each wave loads per K-step
-    constexpr int LPT = 2 + NBL;            // DMA instructions per wave per K-step
-    __shared__ __attribute__((aligned(16))) char lds[G_STAGES * STAGE_BYTES];
+    constexpr int NAL = APIECES / 4, NBL = BPIECES / 4;       // pieces each wave loads per K-step
+    constexpr int LPT = NAL + NBL;          // DMA instructions per wave per K-step
+    extern __shared__ __attribute__((aligned(16))) char lds[];
 
     int tm, tn;
     tile_coords(p, tm, tn);
@@ -292,62 +313,83 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int koff = (lane >> 4) * 8;       // this lane's k offset inside a K-step
 
     // ---- per-lane DMA sources -------------------------------------------------
+    // Piece q of this wave covers rows 8*(4*wave+q) .. +7; lane i fetches row i>>3, source chunk
+    // (i&7) ^ swz with swz = ((row >> 1) & 7) = 4*(q&1) + (i>>4): two distinct k offsets per lane.
     // Address selection is pure integer arithmetic (zero + ((real - zero) & mask)): a ?: on the
     // pointer lets the compiler branch around the DMA, and every wave must issue exactly LPT DMA
     // instructions per step for the counted wait to mean anything.
     const uintptr_t zaddr = (uintptr_t)avsr_zero_page;
-    uintptr_t baseA[2];
-    long stepA[2];
-    ConvRow crow[2];
-    int kh = 0, kw = 0, cc = 0;
+    const int kofs[2] = {(((lane & 7) ^ (lane >> 4)) * 8), (((lane & 7) ^ (4 + (lane >> 4))) * 8)};
+    uintptr_t baseA[NAL];
+    long stepA[NAL];
+    ConvRow crow[NAL];
+    int kh[2] = {0, 0}, kw[2] = {0, 0}, cc[2] = {0, 0};
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + (2 * wave + i) * 16 + (lane & 15);
-        if constexpr (CONV) { crow[i] = conv_row(p, m); baseA[i] = 0; stepA[i] = 0; }
+    for (int q = 0; q < NAL; ++q) {
+        const int m = m0 + (NAL * wave + q) * 8 + (lane >> 3);
+        if constexpr (CONV) { crow[q] = conv_row(p, m); baseA[q] = 0; stepA[q] = 0; }
         else {
             const long live = -(long)(m < p.M);
-            baseA[i] = zaddr + (((uintptr_t)(A + (long)m * p.lda + koff) - zaddr) & (uintptr_t)live);
-            stepA[i] = (long)(G_BK * sizeof(bf16_t)) & live;
+            baseA[q] = zaddr + (((uintptr_t)(A + (long)m * p.lda + kofs[q & 1]) - zaddr) & (uintptr_t)live);
+            stepA[q] = (long)(G_BK * sizeof(bf16_t)) & live;
         }
     }
-    if constexpr (CONV) conv_col(p, koff, kh, kw, cc);
+    if constexpr (CONV) {
+        conv_col(p, kofs[0], kh[0], kw[0], cc[0]);
+        conv_col(p, kofs[1], kh[1], kw[1], cc[1]);
+    }
     uintptr_t baseB[NBL];
     long stepB[NBL];
 #pragma unroll
-    for (int i = 0; i < NBL; ++i) {
-        const int n = n0 + (NBL * wave + i) * 16 + (lane & 15);
+    for (int q = 0; q < NBL; ++q) {
+        const int n = n0 + (NBL * wave + q) * 8 + (lane >> 3);
         const long live = -(long)(n < p.N);
-        baseB[i] = zaddr + (((uintptr_t)(B + (long)n * p.ldb + koff) - zaddr) & (uintptr_t)live);
-        stepB[i] = (long)(G_BK * sizeof(bf16_t)) & live;
+        baseB[q] = zaddr + (((uintptr_t)(B + (long)n * p.ldb + kofs[q & 1]) - zaddr) & (uintptr_t)live);
+        stepB[q] = (long)(G_BK * sizeof(bf16_t)) & live;
     }
     const int nk = (p.K + G_BK - 1) / G_BK;
 
-    auto issue = [&](int kt) {              // DMA the operands of K-step kt into stage kt % 4
-        char* st = lds + (kt & (G_STAGES - 1)) * STAGE_BYTES;
-        const int kk = kt * G_BK + koff;
-        const uintptr_t kin = (uintptr_t)(-(long)(kk < p.K));
+    // K a multiple of the K-step: no per-lane K-tail mask is needed, and steps past the last one simply
+    // re-load the last real step into a stage nobody reads any more (keeps the wait count constant).
+    const bool ktail = (p.K % G_BK) != 0;
+    auto issue = [&](int kt) {              // DMA the operands of K-step kt into stage kt % G_NST
+        char* st = lds + (kt % G_NST) * STAGE_BYTES;
+        const int ks = ktail ? kt : min(kt, nk - 1);
+        uintptr_t kin[2] = {~(uintptr_t)0, ~(uintptr_t)0};
+        if (ktail) {
+            kin[0] = (uintptr_t)(-(long)(kt * G_BK + kofs[0] < p.K));
+            kin[1] = (uintptr_t)(-(long)(kt * G_BK + kofs[1] < p.K));
+        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int q = 0; q < NAL; ++q) {
             uintptr_t a;
             if constexpr (CONV) {
-                const int ih = crow[i].ih0 + kh, iw = crow[i].iw0 + kw;
-                const bool ok = crow[i].ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-                const uintptr_t real = (uintptr_t)(A + ((long)(crow[i].base + ih * p.W + iw)) * p.Cc + cc);
-                a = zaddr + ((real - zaddr) & kin & (uintptr_t)(-(long)ok));
-            } else a = zaddr + ((baseA[i] + (uintptr_t)(kt * stepA[i]) - zaddr) & kin);
-            __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (2 * wave + i) * 1024), 16, 0, 0);
+                const int ih = crow[q].ih0 + kh[q & 1], iw = crow[q].iw0 + kw[q & 1];
+                const bool ok = crow[q].ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                const uintptr_t real = (uintptr_t)(A + ((long)(crow[q].base + ih * p.W + iw)) * p.Cc + cc[q & 1]);
+                a = zaddr + ((real - zaddr) & kin[q & 1] & (uintptr_t)(-(long)ok));
+            } else {
+                a = baseA[q] + (uintptr_t)((long)ks * stepA[q]);
+                if (ktail) a = zaddr + ((a - zaddr) & kin[q & 1]);
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (NAL * wave + q) * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < NBL; ++i) {
-            const uintptr_t a = zaddr + ((baseB[i] + (uintptr_t)(kt * stepB[i]) - zaddr) & kin);
-            __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (APIECES + NBL * wave + i) * 1024), 16, 0, 0);
+        for (int q = 0; q < NBL; ++q) {
+            uintptr_t a = baseB[q] + (uintptr_t)((long)ks * stepB[q]);
+            if (ktail) a = zaddr + ((a - zaddr) & kin[q & 1]);
+            __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (APIECES + NBL * wave + q) * 1024), 16, 0, 0);
         }
-        if constexpr (CONV) {               // advance the (tap, channel) cursor by one K-step
-            cc += G_BK;
-            while (cc >= p.Cc) { cc -= p.Cc; if (++kw == p.KW) { kw = 0; ++kh; } }
+        if constexpr (CONV) {               // advance the two (tap, channel) cursors by one K-step
+            if (ktail || kt < nk - 1) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    cc[e] += G_BK;
+                    while (cc[e] >= p.Cc) { cc[e] -= p.Cc; if (++kw[e] == p.KW) { kw[e] = 0; ++kh[e]; } }
+                }
+            }
         }
     };
 
@@ -357,25 +399,45 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    issue(0); issue(1); issue(2);           // steps past nk read the zero page: the wait count stays constant
-    for (int kt = 0; kt < nk; ++kt) {
-        if constexpr (LPT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __builtin_amdgcn_s_barrier();       // every wave's pieces of step kt have landed; step kt-1 is fully read
-        issue(kt + 3);                      // refills the stage step kt-1 used
-        const char* st = lds + (kt & (G_STAGES - 1)) * STAGE_BYTES;
-        bf16x8 xf[4], wf[NJ];
+    // fragment read offsets: row 16*s + (lane&15), chunk position (4*ks + (lane>>4)) ^ ((lane&15)>>1)
+    const int frow = (lane & 15) * 128;
+    const int fpos[2] = {(((lane >> 4)) ^ ((lane & 15) >> 1)) * 16, ((4 + (lane >> 4)) ^ ((lane & 15) >> 1)) * 16};
+
+    auto compute = [&](const char* st, int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(st + (wm * 4 + i) * 1024 + lane * 16);
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xf[4], wf[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) wf[j] = *(const bf16x8*)(st + (APIECES + wn * NJ + j) * 1024 + lane * 16);
+            for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(st + (wm * 4 + i) * 2048 + frow + fpos[ks]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < NJ; ++j) wf[j] = *(const bf16x8*)(st + APIECES * 1024 + (wn * NJ + j) * 2048 + frow + fpos[ks]);
+            if (G_NST > 1 && ks == 0) issue(kt + G_NST - 1);   // refill the stage the previous step used
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if constexpr (G_NST == 1) {
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_s_barrier();       // the previous step is fully read
+            issue(kt);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();       // every wave's pieces have landed
+            compute(lds, kt);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < G_NST - 1; ++s) issue(s);
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt<LPT * (G_NST - 2)>();    // step kt has landed for this wave ...
+            __builtin_amdgcn_s_barrier();       // ... and for every wave; step kt-1 is fully read
+            compute(lds + (kt % G_NST) * STAGE_BYTES, kt);
+        }
+        wait_vmcnt<0>();                        // drain the re-loaded steps before the LDS is reused
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-page steps before the LDS is reused
     epilogue_tile<BN_, OutT>(p, acc, lds, m0, n0, tm, cbase, lane, wave);
 }
 
@@ -521,20 +583,33 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     hipStream_t s = (hipStream_t)stream;
     const bool of = g->out_dtype == AVSR_F32;
 #define LAUNCH(K, CV, OT) hipLaunchKernelGGL((K<CV, OT>), grid, block, 0, s, p)
-#define LAUNCHB(BNV, CV, OT) hipLaunchKernelGGL((gemm_bf16_kernel<BNV, CV, OT>), grid, block, 0, s, p)
+#define LAUNCHB(BNV, NSTV, CV, OT)                                                                             \
+    do {                                                                                                       \
+        static bool attr_set = false;                                                                          \
+        constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV>();                                                 \
+        auto kfn = gemm_bf16_kernel<BNV, NSTV, CV, OT>;                                                        \
+        if (!attr_set) {                                                                                       \
+            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)   \
+                != hipSuccess) return AVSR_EHIP;                                                               \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
+    } while (0)
+#define LAUNCH_CV_OT(BNV, NSTV)                                                                                \
+    do {                                                                                                       \
+        if (conv) { if (of) LAUNCHB(BNV, NSTV, true, float); else LAUNCHB(BNV, NSTV, true, bf16_t); }          \
+        else      { if (of) LAUNCHB(BNV, NSTV, false, float); else LAUNCHB(BNV, NSTV, false, bf16_t); }        \
+    } while (0)
     if (bf) {
-        if (bn == 64) {
-            if (conv) { if (of) LAUNCHB(64, true, float); else LAUNCHB(64, true, bf16_t); }
-            else      { if (of) LAUNCHB(64, false, float); else LAUNCHB(64, false, bf16_t); }
-        } else {
-            if (conv) { if (of) LAUNCHB(128, true, float); else LAUNCHB(128, true, bf16_t); }
-            else      { if (of) LAUNCHB(128, false, float); else LAUNCHB(128, false, bf16_t); }
-        }
+        const bool single = ntiles * g->batch >= G_NST_SWITCH_TILES;
+        if (bn == 64) { if (single) LAUNCH_CV_OT(64, 1); else LAUNCH_CV_OT(64, 2); }
+        else          { if (single) LAUNCH_CV_OT(128, 1); else LAUNCH_CV_OT(128, 2); }
     } else {
         if (conv) { if (of) LAUNCH(gemm_f32_kernel, true, float); else LAUNCH(gemm_f32_kernel, true, bf16_t); }
         else      { if (of) LAUNCH(gemm_f32_kernel, false, float); else LAUNCH(gemm_f32_kernel, false, bf16_t); }
     }
 #undef LAUNCH
 #undef LAUNCHB
+#undef LAUNCH_CV_OT
     return avsr_launch_status();
 }

@@ -122,10 +122,10 @@ class MoCoVisualFrontend(nn.Module):
         return ops.bn_apply(raw, aff[0], aff[1], residual=residual, relu=relu, out=raw)
 
     @torch.no_grad()
-    def run_stem(self, video):
+    def run_stem(self, video, pk=None):
         """frontend3D on fp32 video [B,T,3,H,W] -> NHWC [B*T, H/4, W/4, 64] in the compute dtype."""
         dtype = self.compute_dtype
-        pk = self._pack(dtype)
+        pk = pk or self._pack(dtype)
         bn0 = self.frontend3D[1]
         if not self.training:
             sc, sh = self._fold(bn0)
@@ -138,9 +138,9 @@ class MoCoVisualFrontend(nn.Module):
         return ops.maxpool3x3s2(raw, scale=aff[0], shift=aff[1])
 
     @torch.no_grad()
-    def run_block(self, index, y):
+    def run_block(self, index, y, pk=None):
         """One Bottleneck (index 0..15 over layer1..layer4) on an NHWC tensor."""
-        pk = self._pack(self.compute_dtype)
+        pk = pk or self._pack(self.compute_dtype)
         e = pk["blocks"][index]
         blk = self._blocks[index]
         idt = y
@@ -158,9 +158,10 @@ class MoCoVisualFrontend(nn.Module):
             x = x.squeeze(1)
         B, T = x.shape[0], x.shape[1]
         video = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
-        y = self.run_stem(video)
+        pk = self._pack(self.compute_dtype)        # one weight-version check per forward
+        y = self.run_stem(video, pk)
         for i in range(len(self._blocks)):
-            y = self.run_block(i, y)
+            y = self.run_block(i, y, pk)
         if self.training:   # one fused increment for all 54 counters
             torch._foreach_add_([m.num_batches_tracked for m in self.modules()
                                  if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d))], 1)
