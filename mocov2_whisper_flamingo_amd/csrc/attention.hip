@@ -41,23 +41,35 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
     f32x16 oacc[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
-    float m2 = -INFINITY, lsum = 0.f;                         // running max (log2 units), partial row sum
+    float mrun = -INFINITY, lsum = 0.f;                       // running max (raw score units), partial row sum
     const float sc2 = scale * LOG2E;
     const int lc = t & 7, lr = t >> 3;                        // staging: chunk, row (+32)
     const bf16_t* Kb = K + (long)b * Tk * ldk + h * HD;
     const bf16_t* Vb = V + (long)b * Tk * ldv + h * HD;
     const uint8_t* mb = mask ? mask + (long)b * Tk : nullptr;
 
-    for (int kv0 = 0; kv0 < Tk; kv0 += 64) {
-        __syncthreads();
+    // register prefetch of the next K/V tile: issued before the current tile's math, written to LDS
+    // after it, so the global-load latency hides under the MFMA / softmax work
+    bf16x8 kreg[2], vreg[2];
+    auto prefetch = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = lr + 32 * i, key = kv0 + row;
+            const int key = kv0 + lr + 32 * i;
             const bool ok = key < Tk;
-            *(bf16x8*)&Ks[k_off(row, lc)] = ok ? *(const bf16x8*)(Kb + (long)key * ldk + lc * 8) : zero8;
-            *(bf16x8*)&Vs[v_off(row, lc)] = ok ? *(const bf16x8*)(Vb + (long)key * ldv + lc * 8) : zero8;
+            kreg[i] = ok ? *(const bf16x8*)(Kb + (long)key * ldk + lc * 8) : zero8;
+            vreg[i] = ok ? *(const bf16x8*)(Vb + (long)key * ldv + lc * 8) : zero8;
+        }
+    };
+    prefetch(0);
+    for (int kv0 = 0; kv0 < Tk; kv0 += 64) {
+        __syncthreads();                                      // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(bf16x8*)&Ks[k_off(lr + 32 * i, lc)] = kreg[i];
+            *(bf16x8*)&Vs[v_off(lr + 32 * i, lc)] = vreg[i];
         }
         __syncthreads();
+        if (kv0 + 64 < Tk) prefetch(kv0 + 64);
 
         f32x16 sacc[2];
 #pragma unroll
@@ -70,48 +82,55 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
                 sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[st], 0, 0, 0);
             }
         }
-        // sacc[st][reg] = S[q][key = kv0 + 32 st + (reg&3) + 8 (reg>>2) + 4 hf]
-        float mx = -INFINITY;
+        // sacc[st][reg] = S[q][key = kv0 + 32 st + (reg&3) + 8 (reg>>2) + 4 hf]   (raw, unscaled)
+        if (mb || kv0 + 64 > Tk) {                            // block-uniform: only masked / tail tiles pay for this
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = kv0 + 32 * st + (i & 3) + 8 * (i >> 2) + 4 * hf;
-                const bool dead = key >= Tk || (mb && mb[key < Tk ? key : 0]);
-                const float s = dead ? -INFINITY : sacc[st][i] * sc2;
-                sacc[st][i] = s;
-                mx = fmaxf(mx, s);
-            }
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kv0 + 32 * st + (i & 3) + 8 * (i >> 2) + 4 * hf;
+                    const bool dead = key >= Tk || (mb && mb[key < Tk ? key : 0]);
+                    if (dead) sacc[st][i] = -INFINITY;
+                }
+        }
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[1][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(m2, mx);
-        const float msafe = mnew == -INFINITY ? 0.f : mnew;
-        const float alpha = exp2f(m2 - msafe);
-        m2 = mnew;
+        if (__any(mx > mrun)) {                               // some row's maximum moved: rescale what is accumulated
+            const float mnew = fmaxf(mrun, mx);
+            const float alpha = mnew > mrun ? exp2f((mrun - mnew) * sc2) : 1.0f;
+            mrun = mnew;
+            lsum *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+        }
+        const float msc = mrun == -INFINITY ? 0.f : mrun * sc2;
         float ps = 0.f;
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { const float p = exp2f(sacc[st][i] - msafe); sacc[st][i] = p; ps += p; }
-        lsum = lsum * alpha + ps;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+            for (int i = 0; i < 16; ++i) { const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[st][i], sc2, -msc)); sacc[st][i] = pv; ps += pv; }
+        lsum += ps;
 
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 pf;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)sacc[st][8 * s + j];
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)sacc[st][8 * s2 + j];
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    // V^T fragment: element j <-> key 32 st + 16 s + 8 (j>>2) + 4 hf + (j&3), d = 32 db + r
+                    // V^T fragment: element j <-> key 32 st + 16 s2 + 8 (j>>2) + 4 hf + (j&3), d = 32 db + r
                     const int i16 = lane & 15;
                     const int col = 32 * db + 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
                     bf16x8 vf;
 #pragma unroll
                     for (int jh = 0; jh < 2; ++jh) {
-                        const int row = 32 * st + 16 * s + 8 * jh + 4 * hf + (i16 >> 2);
+                        const int row = 32 * st + 16 * s2 + 8 * jh + 4 * hf + (i16 >> 2);
                         const bf16_t* ap = &Vs[v_off(row, col >> 3) + (col & 7)];
                         const s16x4 tr = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (__attribute__((address_space(3))) s16x4*)(ap));
@@ -136,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
                 *(bf16x4*)(op + 32 * db + 8 * g + 4 * hf) = o;
             }
         if (lse && hf == 0)
-            lse[((long)b * H + h) * Tq + q] = lsum > 0.f ? m2 / LOG2E + logf(lsum) : INFINITY;
+            lse[((long)b * H + h) * Tq + q] = lsum > 0.f ? mrun * scale + logf(lsum) : INFINITY;
     }
 }
 

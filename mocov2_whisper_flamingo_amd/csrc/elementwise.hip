@@ -36,20 +36,30 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ x
     }
 }
 
-// out[n] (+)= sum_m x[m][n]; one block per 64 columns, 4 waves split the rows.
+// out[n] (+)= sum_m x[m][n]; one 1024-thread block per 64 columns, 16 waves split the rows.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ld, int M, int N, float* __restrict__ out,
-                                                     int accumulate) {
-    __shared__ float part[4][64];
+__global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ x, long ld, int M, int N, float* __restrict__ out,
+                                                      int accumulate) {
+    __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (n < N)
-        for (int m = w; m < M; m += 4) s += to_f32<T>(x[(long)m * ld + n]);
-    part[w][lane] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (n < N) {
+        int m = w;
+        for (; m + 48 < M; m += 64) {
+            s0 += to_f32<T>(x[(long)m * ld + n]);
+            s1 += to_f32<T>(x[(long)(m + 16) * ld + n]);
+            s2 += to_f32<T>(x[(long)(m + 32) * ld + n]);
+            s3 += to_f32<T>(x[(long)(m + 48) * ld + n]);
+        }
+        for (; m < M; m += 16) s0 += to_f32<T>(x[(long)m * ld + n]);
+    }
+    part[w][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (w == 0 && n < N) {
-        const float t = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][lane];
         out[n] = accumulate ? out[n] + t : t;
     }
 }
@@ -195,7 +205,7 @@ extern "C" int avsr_colsum(avsr_stream_t stream, int dtype, const void* x, int64
                            int accumulate) {
     if (!x || !out || M <= 0 || N <= 0) return AVSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)((N + 63) / 64)), block(256);
+    dim3 grid((unsigned)((N + 63) / 64)), block(1024);
     if (dtype == AVSR_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)x, (long)ld, (int)M, (int)N, out, accumulate);
     else if (dtype == AVSR_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, (long)ld, (int)M, (int)N, out, accumulate);
     else return AVSR_EINVAL;

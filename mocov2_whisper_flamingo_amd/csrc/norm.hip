@@ -130,14 +130,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TG* __restrict
             }
         }
     }
+    // fold the block's 4 waves through LDS (lane l of every wave owns the same columns), then one
+    // atomic per column per block
+    __shared__ float red[2][3][64 * 4 * LN_MAXV];
+    const int w = threadIdx.x >> 6;
+    if (w > 0) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(dgamma + c * 4 + e, dg[i][e]);
-                atomicAdd(dbeta + c * 4 + e, db[i][e]);
+                for (int e = 0; e < 4; ++e) { red[0][w - 1][c * 4 + e] = dg[i][e]; red[1][w - 1][c * 4 + e] = db[i][e]; }
+            }
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = c * 4 + e;
+                    atomicAdd(dgamma + k, dg[i][e] + red[0][0][k] + red[0][1][k] + red[0][2][k]);
+                    atomicAdd(dbeta + k, db[i][e] + red[1][0][k] + red[1][1][k] + red[1][2][k]);
+                }
             }
         }
     }
@@ -167,8 +185,8 @@ extern "C" int avsr_layernorm_bwd(avsr_stream_t stream, int x_dtype, int g_dtype
                                   void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int64_t D) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return AVSR_EINVAL;
     if (D % 4 || D > 64 * 4 * LN_MAXV || ldx % 4 || lddy % 4 || lddx % 4) return AVSR_EUNSUPPORTED;
-    long nb = (rows + 3) / 4;
-    if (nb > 256) nb = 256;
+    long nb = (rows + 31) / 32;      // ~8 rows per wave: few blocks, few atomics
+    if (nb > 128) nb = 128;
     dim3 grid((unsigned)nb), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define L(TX, TG) hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TG>), grid, block, 0, s, (const TG*)dy, (long)lddy, (const TX*)x, \
@@ -219,6 +237,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float s = 0.f, q = 0.f;
+#pragma unroll 8
     for (int p = 0; p < nparts; ++p) { s += sum[(long)p * row_stride + c]; q += sumsq[(long)p * row_stride + c]; }
     const float mean = s / count;
     float var = q / count - mean * mean;

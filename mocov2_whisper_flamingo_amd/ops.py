@@ -28,7 +28,8 @@ def _p(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # raw hipStream_t of torch's current stream (the fast path: no Stream object is built)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _need_cuda(*ts):

@@ -24,4 +24,4 @@ t2 = time.perf_counter()
 print(f"enqueue {1e3*(t1-t0)/5:.2f} ms/step, total {1e3*(t2-t0)/5:.2f} ms/step")
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable(); step(); pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(25)
+pstats.Stats(pr).sort_stats('tottime').print_stats(30)
