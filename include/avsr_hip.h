@@ -205,6 +205,10 @@ int avsr_gated_residual_fwd(avsr_stream_t stream, int dtype, const void* x, cons
                             void* out, int64_t n, float p_drop, uint64_t seed);
 int avsr_gated_residual_bwd(avsr_stream_t stream, int dtype, const void* dout, const void* y, const float* gate,
                             void* dy, float* dgate, int64_t n, float p_drop, uint64_t seed);
+/* out[i] = sum_s parts[s*part_stride + i] (+ bias[i % ncol]): combines the fp32 partial products of a
+ * GEMM whose K dimension was split over the batch index (few tiles, very long K: the head's dX) */
+int avsr_sum_parts(avsr_stream_t stream, int out_dtype, const float* parts, int64_t part_stride, int64_t S,
+                   const float* bias, int64_t ncol, void* out, int64_t n);
 /* out = a + b + c (c may be NULL)  (models/av_net.py:106) */
 int avsr_add3(avsr_stream_t stream, int dtype, const void* a, const void* b, const void* c, void* out, int64_t n);
 

@@ -121,6 +121,23 @@ __global__ __launch_bounds__(256) void add3_kernel(const T* __restrict__ a, cons
         out[i] = from_f32<T>(to_f32<T>(a[i]) + to_f32<T>(b[i]) + (c ? to_f32<T>(c[i]) : 0.f));
 }
 
+// out[i] = sum_s parts[s][i] (+ bias[i % ncol]); combines split-K partial products
+template <typename TO>
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ parts, long part_stride, int S,
+                                                        const float* __restrict__ bias, int ncol, TO* __restrict__ out, long n) {
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        f32x4 a = *(const f32x4*)(parts + i);
+        for (int s = 1; s < S; ++s) { const f32x4 b = *(const f32x4*)(parts + (long)s * part_stride + i); a += b; }
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += bias[(i + e) % ncol];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[i + e] = from_f32<TO>(a[e]);
+    }
+}
+
 // out[0] += sum(x^2)
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
     __shared__ float red[16];
@@ -260,6 +277,18 @@ extern "C" int avsr_add3(avsr_stream_t stream, int dtype, const void* a, const v
     dim3 grid(grid_for(n, 256, 4096)), block(256);
     if (dtype == AVSR_F32) hipLaunchKernelGGL(add3_kernel<float>, grid, block, 0, s, (const float*)a, (const float*)b, (const float*)c, (float*)out, (long)n);
     else if (dtype == AVSR_BF16) hipLaunchKernelGGL(add3_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c, (bf16_t*)out, (long)n);
+    else return AVSR_EINVAL;
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_sum_parts(avsr_stream_t stream, int out_dtype, const float* parts, int64_t part_stride, int64_t S,
+                              const float* bias, int64_t ncol, void* out, int64_t n) {
+    if (!parts || !out || S <= 0 || n <= 0 || (bias && ncol <= 0)) return AVSR_EINVAL;
+    if (n % 4 || part_stride % 4 || ((uintptr_t)parts % 16)) return AVSR_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(grid_for(n, 1024, 4096)), block(256);
+    if (out_dtype == AVSR_F32) hipLaunchKernelGGL(sum_parts_kernel<float>, grid, block, 0, s, parts, (long)part_stride, (int)S, bias, (int)ncol, (float*)out, (long)n);
+    else if (out_dtype == AVSR_BF16) hipLaunchKernelGGL(sum_parts_kernel<bf16_t>, grid, block, 0, s, parts, (long)part_stride, (int)S, bias, (int)ncol, (bf16_t*)out, (long)n);
     else return AVSR_EINVAL;
     return avsr_launch_status();
 }

@@ -35,12 +35,22 @@ class WeightCache:
         with torch.no_grad():
             w = p.detach()
             wc = w if self.dtype == torch.float32 else ops.cast(w, self.dtype)
-            wct = ops.transpose2d(w, dtype=self.dtype, pad_to=8)
+            # big vocabulary heads: pad N so the dX product can split its K (= N) 16 ways in 64-element steps
+            wct = ops.transpose2d(w, dtype=self.dtype, pad_to=1024 if w.shape[0] > 16384 else 8)
         self._store[key] = (ver, wc, wct)
         return wc, wct
 
     def clear(self):
         self._store.clear()
+
+
+def _dx_gemm(dy, wct):
+    """dX = dY @ W.  Few output tiles with a very long reduction (the vocabulary head: M x 512 over
+    K = 52k) would leave the chip idle; split K over 16 batched GEMMs and sum the partials."""
+    K = dy.shape[1]
+    if K >= 16384 and K % (16 * 64) == 0 and dy.shape[0] * wct.shape[0] <= 1 << 20:
+        return ops.gemm_nt_splitk(dy, wct, 16)
+    return ops.gemm_nt(dy, wct)
 
 
 class LinearFn(Function):
@@ -73,7 +83,7 @@ class LinearFn(Function):
             pad[:, :N].copy_(dy)
             dy = pad[:, :N]
         dyk = dy if Np == N else torch.as_strided(dy, (M, Np), (dy.stride(0), 1))   # padding columns are zero
-        dx = ops.gemm_nt(dyk, wct) if ctx.needs_input_grad[0] else None
+        dx = _dx_gemm(dyk, wct) if ctx.needs_input_grad[0] else None
         dyt = ops.transpose2d(dy, pad_to=8)                     # [N, Mp]
         xt = ops.transpose2d(x, pad_to=8)                       # [K, Mp]
         dw = ops.gemm_nt(dyt, xt, out_dtype=torch.float32)      # [N, K]
@@ -187,7 +197,7 @@ class HeadLossFn(Function):
         ge = g_ce.reshape(1).float().contiguous() if g_ce is not None else torch.zeros(1, device=x.device)
         dl = ops.head_loss_bwd(logits, targets, input_lengths, target_lengths, ws, x.dtype, label_smoothing=ls,
                                up_ctc=gc, up_ce=ge, ld_out=ld)                       # [B*T, ld], pad columns zero
-        dx = ops.gemm_nt(dl, wct)
+        dx = _dx_gemm(dl, wct)
         dlt = ops.transpose2d(dl[:, :V], pad_to=8)
         xt = ops.transpose2d(x, pad_to=8)
         dw = ops.gemm_nt(dlt, xt, out_dtype=torch.float32)

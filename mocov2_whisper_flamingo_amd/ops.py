@@ -102,6 +102,24 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
     return out
 
 
+def gemm_nt_splitk(a, b, S, out_dtype=None):
+    """a [M,K] @ b [N,K]^T with K cut into S slices computed as S batched GEMMs (fp32 partials) and
+    summed: for products with few output tiles and a very long K.  K/S must be a multiple of 8."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = b.shape[0]
+    Kc = K // S
+    if Kc * S != K or Kc % 8 or a.stride(1) != 1 or b.stride(1) != 1 or (M * N) % 4:
+        raise ValueError("unsupported split")
+    a3 = torch.as_strided(a, (S, M, Kc), (Kc, a.stride(0), 1))
+    b3 = torch.as_strided(b, (S, N, Kc), (Kc, b.stride(0), 1))
+    parts = gemm_nt(a3, b3, out_dtype=torch.float32)                  # [S, M, N]
+    out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
+    check(lib.avsr_sum_parts(_stream(), _DT[out.dtype], parts.data_ptr(), M * N, S, None, 0, out.data_ptr(), M * N),
+          "avsr_sum_parts")
+    return out
+
+
 def gemm_stats_slabs(M, N, dtype, device):
     """Zero-free allocation of the [2, parts, N] partial-sum slabs a gemm_nt / conv_nhwc launch with
     M output rows fills completely (pass ``col_stats=(s[0], s[1])``)."""
