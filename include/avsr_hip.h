@@ -128,6 +128,34 @@ int avsr_attn_bwd(avsr_stream_t stream, int dtype, const void* Q, int64_t ldq, c
                   int64_t Tk, int64_t head_dim, float scale, float p_drop, uint64_t seed);
 
 /* ------------------------------------------------------------------------
+ * Mel front end: waveform [batch, n_samples] fp32 -> 80-bin mel features.
+ *  AVSR_MEL_WHISPER  WhisperFeatureExtractor._torch_extract_fbank_features
+ *    (transformers feature_extraction_whisper.py:135-168; reference call site
+ *    datamodule/av_dataset.py:47-51): periodic-hann STFT 400/160 with centre +
+ *    reflect padding, power of frames 0..n_samples/160-1, Slaney mel bank,
+ *    log10(max(.,1e-10)), floor at (clip max - 8), (x+4)/4.
+ *  AVSR_MEL_SPEC_LN  torchaudio MelSpectrogram(16000, 400, 400, 160, n_mels 80)
+ *    + pad/trim to n_frames_out + layer_norm over the whole [frames, 80] clip,
+ *    eps 1e-8 (datamodule/transforms.py:115-121,99-110,131).
+ * Samples [n_valid, n_samples) read as zero (the extractor's zero padding to
+ * 30 s); reflection happens at n_samples.  out element (b, t, m) is written to
+ * out[b*out_stride_b + t*out_stride_t + m*out_stride_m]: strides (80*T, 80, 1)
+ * give the channels-last [B,T,80] the encoder consumes, (80*T, 1, T) the
+ * reference's [B,80,T].  The two constant tables (DFT matrix with the window
+ * folded in, mel bank; both in MFMA fragment order) are filled once by
+ * avsr_logmel_tables; workspace: avsr_logmel_workspace_floats() floats.
+ * ---------------------------------------------------------------------- */
+enum { AVSR_MEL_WHISPER = 0, AVSR_MEL_SPEC_LN = 1 };
+int64_t avsr_logmel_dft_table_floats(void);
+int64_t avsr_logmel_mel_table_floats(void);
+int avsr_logmel_tables(avsr_stream_t stream, int variant, float* dft_table, float* mel_table);
+int64_t avsr_logmel_workspace_floats(int64_t batch, int64_t n_frames_out);
+int avsr_logmel_fwd(avsr_stream_t stream, int variant, int out_dtype, const float* wave, int64_t wave_stride,
+                    int64_t n_samples, int64_t n_valid, int64_t batch, const float* dft_table,
+                    const float* mel_table, void* out, int64_t out_stride_b, int64_t out_stride_t,
+                    int64_t out_stride_m, int64_t n_frames_out, float* workspace);
+
+/* ------------------------------------------------------------------------
  * Visual frontend pieces (models/moco_visual_frontend.py).
  * avsr_stem3d_fwd: Conv3d(3,64,(5,3,3),s(1,2,2),p(2,3,3),bias=False) (:15) on
  *   video [B,T,3,H,W] fp32 -> NHWC [B*T,OH,OW,64]; weight_packed is the

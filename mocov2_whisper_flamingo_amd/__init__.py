@@ -4,10 +4,11 @@ HIP kernels (``csrc/``) reached through a C ABI (``include/avsr_hip.h``);
 PyTorch supplies device memory, streams and ``torch.distributed`` only."""
 from . import _lib, ops  # noqa: F401
 from .av_net import AVNet
+from .logmel import LogMelFrontend
 from .gate_cross_attention import GatedCrossAttentionBlock, GatedCrossModalFusion, LayerNorm
 from .moco_visual_frontend import MoCoVisualFrontend
 from .utils import Decoder, PositionalEncoding
 from .whisper_encoder import WhisperConfig, WhisperEncoder, WhisperModel
 
-__all__ = ["AVNet", "GatedCrossAttentionBlock", "GatedCrossModalFusion", "LayerNorm", "MoCoVisualFrontend",
+__all__ = ["AVNet", "GatedCrossAttentionBlock", "GatedCrossModalFusion", "LayerNorm", "LogMelFrontend", "MoCoVisualFrontend",
            "Decoder", "PositionalEncoding", "WhisperConfig", "WhisperEncoder", "WhisperModel", "ops"]

@@ -242,6 +242,40 @@ def stem3d_fwd(video, weight, out_dtype, *, scale=None, shift=None, col_stats=No
     return out
 
 
+MEL_WHISPER, MEL_SPEC_LN = 0, 1
+
+
+def logmel_tables(variant, device):
+    """Constant tables of avsr_logmel_fwd for one variant: (DFT matrix with the hann window folded in, mel bank)."""
+    lib = _lib.load()
+    dft = torch.empty(int(lib.avsr_logmel_dft_table_floats()), dtype=torch.float32, device=device)
+    mel = torch.empty(int(lib.avsr_logmel_mel_table_floats()), dtype=torch.float32, device=device)
+    _need_cuda(dft, mel)
+    check(lib.avsr_logmel_tables(_stream(), variant, dft.data_ptr(), mel.data_ptr()), "avsr_logmel_tables")
+    return dft, mel
+
+
+def logmel_fwd(wave, tables, variant, *, n_samples=None, n_frames=None, out_dtype=torch.float32, channels_last=False):
+    """wave [B, n_valid] fp32 (read as zero-padded to ``n_samples``) -> mel features [B,80,n_frames], or
+    [B,n_frames,80] with ``channels_last``."""
+    lib = _lib.load()
+    _need_cuda(wave, *tables)
+    if wave.dim() != 2 or wave.dtype != torch.float32 or wave.stride(1) != 1:
+        raise ValueError("logmel expects a [B, n] fp32 waveform with unit sample stride")
+    B, n_valid = wave.shape
+    n_samples = int(n_samples or n_valid)
+    if n_frames is None:
+        n_frames = n_samples // 160 if variant == MEL_WHISPER else 3000
+    shape = (B, n_frames, 80) if channels_last else (B, 80, n_frames)
+    out = torch.empty(shape, dtype=out_dtype, device=wave.device)
+    st, sm = (80, 1) if channels_last else (1, n_frames)
+    ws = torch.empty(int(lib.avsr_logmel_workspace_floats(B, n_frames)), dtype=torch.float32, device=wave.device)
+    check(lib.avsr_logmel_fwd(_stream(), variant, _DT[out_dtype], wave.data_ptr(), wave.stride(0), n_samples, n_valid, B,
+                              tables[0].data_ptr(), tables[1].data_ptr(), out.data_ptr(), 80 * n_frames, st, sm,
+                              n_frames, ws.data_ptr()), "avsr_logmel_fwd")
+    return out
+
+
 def maxpool3x3s2(x, *, scale=None, shift=None, out_dtype=None):
     lib = _lib.load()
     N, H, W, C = x.shape
