@@ -111,18 +111,22 @@ int avsr_layernorm_bwd(avsr_stream_t stream, int x_dtype, int g_dtype, const voi
  * (key_padding_mask of nn.MultiheadAttention, models/gate_cross_attention.py:40);
  * a query row whose keys are all masked yields zeros.  lse (optional for the
  * forward, required by the backward): fp32 [B,H,Tq].
- * use_mfma = 1: bf16 flash kernel on v_mfma_f32_32x32x16_bf16, no dropout
- *   (the Whisper encoder self-attention, hf:284-356 / 215-238).
- * use_mfma = 0: exact fp32-math kernel, any dtype, attention dropout with the
- *   counter-based generator keyed by (seed, ((b*H+h)*Tq+q)*Tk+k).
+ * use_mfma = 1: bf16 flash kernels on v_mfma_f32_32x32x16_bf16 (the Whisper
+ *   encoder self-attention, hf:284-356 / 215-238, and the core of the gated
+ *   cross-attention, models/gate_cross_attention.py:40, forward + backward).
+ * use_mfma = 0: exact fp32-math kernels, any dtype.
+ * Attention dropout (p_drop > 0) drops softmax probabilities with a
+ * counter-based generator: element (row = (b*H+h)*Tq + q, key) uses output
+ * (key & 3) of counter row*ceil(Tk/4) + key/4 under `seed`; forward and
+ * backward, MFMA and fp32 kernels all draw the same mask.
  * ---------------------------------------------------------------------- */
 int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
                   int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
                   float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
                   float p_drop, uint64_t seed);
 /* d_ws: fp32 [B,H,Tq] scratch (row sums of dO*O). */
-int avsr_attn_bwd(avsr_stream_t stream, int dtype, const void* Q, int64_t ldq, const void* K, int64_t ldk,
-                  const void* V, int64_t ldv, const void* O, int64_t ldo, const void* dO, int64_t lddo,
+int avsr_attn_bwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
+                  int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo, const void* dO, int64_t lddo,
                   void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv,
                   const uint8_t* key_mask, const float* lse, float* d_ws, int64_t B, int64_t H, int64_t Tq,
                   int64_t Tk, int64_t head_dim, float scale, float p_drop, uint64_t seed);

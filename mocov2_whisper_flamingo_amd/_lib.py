@@ -40,7 +40,7 @@ SIGNATURES = {
     "avsr_layernorm_bwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64]),
     "avsr_attn_fwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
                              _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64]),
-    "avsr_attn_bwd": (_i32, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
+    "avsr_attn_bwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
                              _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64]),
     "avsr_logmel_dft_table_floats": (_i64, []),
     "avsr_logmel_mel_table_floats": (_i64, []),

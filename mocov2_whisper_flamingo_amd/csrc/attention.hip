@@ -6,9 +6,12 @@
 //    and the 32x32 accumulator is, register for register, the B operand of
 //    the O^T = V^T.P^T product (no LDS round trip for P).  V is read from its
 //    row-major LDS tile with the transposing ds_read_b64_tr_b16.
+//    Key-padding mask, attention dropout (four keys per generator call) and
+//    the saved log-sum-exp make it the core of the gated cross-attention too.
+//  * attn_bwd_dq_mfma_kernel / attn_bwd_dkv_mfma_kernel: its backward on the
+//    same transposed scheme, no atomics (each recomputes S and dP).
 //  * attn_*_valu_kernel: exact fp32-math forward / backward (dQ and dK,dV)
-//    with key-padding mask, attention dropout and saved log-sum-exp; used for
-//    the fp32 parity path and for the trainable fusion blocks.
+//    with the same mask / dropout / log-sum-exp semantics: the fp32 parity path.
 //
 // Layout of every operand: element (b, t, h, d) at ptr + (b*T + t)*ld + h*64 + d.
 #include "common.h"
@@ -17,13 +20,46 @@
 #define LOG2E 1.4426950408889634f
 
 // ---------------------------------------------------------------- MFMA ----
+// v_mfma_f32_32x32x16_bf16 fragments (lane = 32*hf + r): A row r / B column r,
+// k = 8*hf + j (j = 0..7); C column r, register i <-> row (i&3) + 8*(i>>2) + 4*hf.
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 1) & 1) << 2)) << 3); }
 
+// A-operand fragment of X^T for a row-major [64 rows][64 cols] LDS tile X stored with v_off: output row
+// (= X column) 32*db + r, contraction index (= X row) follows the C-register order of rows
+// 32*st + 16*s2 .. +15, so a 32x32 accumulator converted to bf16 is directly the matching B operand.
+__device__ __forceinline__ bf16x8 read_tr_frag(const bf16_t* X, int st, int s2, int db, int lane) {
+    const int i16 = lane & 15, hf = lane >> 5;
+    const int col = 32 * db + 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
+    bf16x8 f;
+#pragma unroll
+    for (int jh = 0; jh < 2; ++jh) {
+        const int row = 32 * st + 16 * s2 + 8 * jh + 4 * hf + (i16 >> 2);
+        const bf16_t* ap = &X[v_off(row, col >> 3) + (col & 7)];
+        const s16x4 tr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ap));
+        const bf16x4 tb = __builtin_bit_cast(bf16x4, tr);
+        f[4 * jh + 0] = tb[0]; f[4 * jh + 1] = tb[1]; f[4 * jh + 2] = tb[2]; f[4 * jh + 3] = tb[3];
+    }
+    return f;
+}
+__device__ __forceinline__ bf16x8 acc_to_bf16(const f32x16& a, int s2) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (bf16_t)a[8 * s2 + j];
+    return f;
+}
+// bit (key - kv0) set <=> key of this 64-key tile is padding (>= Tk) or masked; wave-uniform
+__device__ __forceinline__ uint64_t dead_keys(const uint8_t* mb, int kv0, int Tk, int lane) {
+    const int key = kv0 + lane;
+    return __ballot(key >= Tk || (mb && mb[key < Tk ? key : 0]));
+}
+
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
                                                             long ldk, const bf16_t* __restrict__ V, long ldv,
                                                             bf16_t* __restrict__ O, long ldo, const uint8_t* __restrict__ mask,
-                                                            float* __restrict__ lse, int Tq, int Tk, int H, float scale) {
+                                                            float* __restrict__ lse, int Tq, int Tk, int H, float scale,
+                                                            float pdrop, uint64_t seed) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * 64];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * 64];
     const int b = blockIdx.z, h = blockIdx.y;
@@ -47,6 +83,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
     const bf16_t* Kb = K + (long)b * Tk * ldk + h * HD;
     const bf16_t* Vb = V + (long)b * Tk * ldv + h * HD;
     const uint8_t* mb = mask ? mask + (long)b * Tk : nullptr;
+    const float keep_scale = DROP ? 1.0f / (1.0f - pdrop) : 1.0f;
+    const int tk4 = (Tk + 3) >> 2;
+    const uint64_t row = ((uint64_t)b * H + h) * Tq + q;
 
     // register prefetch of the next K/V tile: issued before the current tile's math, written to LDS
     // after it, so the global-load latency hides under the MFMA / softmax work
@@ -84,14 +123,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
         }
         // sacc[st][reg] = S[q][key = kv0 + 32 st + (reg&3) + 8 (reg>>2) + 4 hf]   (raw, unscaled)
         if (mb || kv0 + 64 > Tk) {                            // block-uniform: only masked / tail tiles pay for this
+            const uint64_t dead = dead_keys(mb, kv0, Tk, lane);
+            if (dead) {
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
+                for (int st = 0; st < 2; ++st)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = kv0 + 32 * st + (i & 3) + 8 * (i >> 2) + 4 * hf;
-                    const bool dead = key >= Tk || (mb && mb[key < Tk ? key : 0]);
-                    if (dead) sacc[st][i] = -INFINITY;
-                }
+                    for (int i = 0; i < 16; ++i)
+                        if ((dead >> (32 * st + (i & 3) + 8 * (i >> 2) + 4 * hf)) & 1) sacc[st][i] = -INFINITY;
+            }
         }
         float mx = sacc[0][0];
 #pragma unroll
@@ -113,32 +152,28 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[st][i], sc2, -msc)); sacc[st][i] = pv; ps += pv; }
-        lsum += ps;
+        lsum += ps;                                           // the normaliser is that of the un-dropped softmax
+        if (DROP) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint32_t bits[4];
+                    avsr_philox4(seed, avsr_attn_counter(row, tk4, kv0 + 32 * st + 8 * g + 4 * hf), bits);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        sacc[st][4 * g + e] = avsr_bits_keep(bits[e], pdrop) ? sacc[st][4 * g + e] * keep_scale : 0.f;
+                }
+        }
 
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 pf;
+                const bf16x8 pf = acc_to_bf16(sacc[st], s2);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)sacc[st][8 * s2 + j];
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    // V^T fragment: element j <-> key 32 st + 16 s2 + 8 (j>>2) + 4 hf + (j&3), d = 32 db + r
-                    const int i16 = lane & 15;
-                    const int col = 32 * db + 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
-                    bf16x8 vf;
-#pragma unroll
-                    for (int jh = 0; jh < 2; ++jh) {
-                        const int row = 32 * st + 16 * s2 + 8 * jh + 4 * hf + (i16 >> 2);
-                        const bf16_t* ap = &Vs[v_off(row, col >> 3) + (col & 7)];
-                        const s16x4 tr = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(ap));
-                        const bf16x4 tb = __builtin_bit_cast(bf16x4, tr);
-                        vf[4 * jh + 0] = tb[0]; vf[4 * jh + 1] = tb[1]; vf[4 * jh + 2] = tb[2]; vf[4 * jh + 3] = tb[3];
-                    }
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
-                }
+                for (int db = 0; db < 2; ++db)
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr_frag(Vs, st, s2, db, lane), pf, oacc[db], 0, 0, 0);
             }
     }
     lsum += __shfl_xor(lsum, 32, 64);
@@ -156,6 +191,235 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
             }
         if (lse && hf == 0)
             lse[((long)b * H + h) * Tq + q] = lsum > 0.f ? mrun * scale + logf(lsum) : INFINITY;
+    }
+}
+
+// dQ for 128 query rows per workgroup (one per lane pair), looping over 64-key tiles; also writes the
+// per-row D = dO.O the dK/dV kernel needs.  Transposed like the forward: S^T = K.Q^T and dP^T = V.dO^T put
+// a query in a lane, and the dS^T accumulator is the B operand of dQ^T = K^T.dS^T.
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(
+    const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K, long ldk, const bf16_t* __restrict__ V, long ldv,
+    const bf16_t* __restrict__ O, long ldo, const bf16_t* __restrict__ dO, long lddo, bf16_t* __restrict__ dQ, long lddq,
+    const uint8_t* __restrict__ mask, const float* __restrict__ lse, float* __restrict__ Dout, int Tq, int Tk, int H,
+    float scale, float pdrop, uint64_t seed) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t Kt[64 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * 64];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane & 31, hf = lane >> 5;
+    const int q = blockIdx.x * 128 + wave * 32 + r;
+    const bool qv = q < Tq;
+    const long bh = (long)b * H + h;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    bf16x8 qf[4], dof[4];
+    float dsum = 0.f;
+    {
+        const long qrow = (long)b * Tq + (qv ? q : 0);
+        const bf16_t* qp = Q + qrow * ldq + h * HD + hf * 8;
+        const bf16_t* dp = dO + qrow * lddo + h * HD + hf * 8;
+        const bf16_t* op = O + qrow * ldo + h * HD + hf * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = qv ? *(const bf16x8*)(qp + ks * 16) : zero8;
+            dof[ks] = qv ? *(const bf16x8*)(dp + ks * 16) : zero8;
+            const bf16x8 of = qv ? *(const bf16x8*)(op + ks * 16) : zero8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum = fmaf((float)dof[ks][j], (float)of[j], dsum);
+        }
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    const float l2 = (qv ? lse[bh * Tq + q] : INFINITY) * LOG2E;       // +inf for dead rows: every p is 0
+    if (qv && hf == 0) Dout[bh * Tq + q] = dsum;
+    f32x16 dq[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
+    const float sc2 = scale * LOG2E;
+    const float keep_scale = DROP ? 1.0f / (1.0f - pdrop) : 1.0f;
+    const int tk4 = (Tk + 3) >> 2;
+    const uint64_t row = (uint64_t)bh * Tq + q;
+    const int lc = t & 7, lr = t >> 3;
+    const bf16_t* Kb = K + (long)b * Tk * ldk + h * HD;
+    const bf16_t* Vb = V + (long)b * Tk * ldv + h * HD;
+    const uint8_t* mb = mask ? mask + (long)b * Tk : nullptr;
+
+    for (int kv0 = 0; kv0 < Tk; kv0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = kv0 + lr + 32 * i;
+            const bool ok = key < Tk;
+            const bf16x8 kk = ok ? *(const bf16x8*)(Kb + (long)key * ldk + lc * 8) : zero8;
+            const bf16x8 vv = ok ? *(const bf16x8*)(Vb + (long)key * ldv + lc * 8) : zero8;
+            *(bf16x8*)&Ks[k_off(lr + 32 * i, lc)] = kk;
+            *(bf16x8*)&Kt[v_off(lr + 32 * i, lc)] = kk;
+            *(bf16x8*)&Vs[k_off(lr + 32 * i, lc)] = vv;
+        }
+        __syncthreads();
+        const uint64_t dead = dead_keys(mb, kv0, Tk, lane);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sacc[i] = 0.f; pacc[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)&Ks[k_off(32 * st + r, 2 * ks + hf)];
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
+                const bf16x8 vf = *(const bf16x8*)&Vs[k_off(32 * st + r, 2 * ks + hf)];
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint32_t bits[4];
+                if (DROP) avsr_philox4(seed, avsr_attn_counter(row, tk4, kv0 + 32 * st + 8 * g + 4 * hf), bits);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g + e;
+                    const bool dd = (dead >> (32 * st + 8 * g + 4 * hf + e)) & 1;
+                    const float p = dd ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[i], sc2, -l2));
+                    float dp = pacc[i];
+                    if (DROP) dp = avsr_bits_keep(bits[e], pdrop) ? dp * keep_scale : 0.f;
+                    sacc[i] = p * (dp - dsum) * scale;                     // dS^T
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 dsf = acc_to_bf16(sacc, s2);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr_frag(Kt, st, s2, db, lane), dsf, dq[db], 0, 0, 0);
+            }
+        }
+    }
+    if (qv) {
+        bf16_t* op = dQ + ((long)b * Tq + q) * lddq + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)dq[db][4 * g + e];
+                *(bf16x4*)(op + 32 * db + 8 * g + 4 * hf) = o;
+            }
+    }
+}
+
+// dK, dV for 128 keys per workgroup (a key per lane pair), looping over 64-query tiles:
+// S = Q.K^T and dP = dO.V^T put a key in a lane; the dropped-P and dS accumulators are the B operands
+// of dV^T = dO^T.P and dK^T = Q^T.dS.
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(
+    const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K, long ldk, const bf16_t* __restrict__ V, long ldv,
+    const bf16_t* __restrict__ dO, long lddo, bf16_t* __restrict__ dK, long lddk, bf16_t* __restrict__ dV, long lddv,
+    const uint8_t* __restrict__ mask, const float* __restrict__ lse, const float* __restrict__ Dsum, int Tq, int Tk, int H,
+    float scale, float pdrop, uint64_t seed) {
+    __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t Qt[64 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t Os[64 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t Ot[64 * 64];
+    __shared__ float Ls[64], Ds[64];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane & 31, hf = lane >> 5;
+    const int key = blockIdx.x * 128 + wave * 32 + r;
+    const bool kvalid = key < Tk;
+    const long bh = (long)b * H + h;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool dead = !kvalid || (mask && mask[(long)b * Tk + key]);
+
+    bf16x8 kf[4], vf[4];
+    {
+        const long krow = (long)b * Tk + (kvalid ? key : 0);
+        const bf16_t* kp = K + krow * ldk + h * HD + hf * 8;
+        const bf16_t* vp = V + krow * ldv + h * HD + hf * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = kvalid ? *(const bf16x8*)(kp + ks * 16) : zero8;
+            vf[ks] = kvalid ? *(const bf16x8*)(vp + ks * 16) : zero8;
+        }
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+    const float sc2 = scale * LOG2E;
+    const float keep_scale = DROP ? 1.0f / (1.0f - pdrop) : 1.0f;
+    const int tk4 = (Tk + 3) >> 2;
+    const int lc = t & 7, lr = t >> 3;
+    const bf16_t* Qb = Q + (long)b * Tq * ldq + h * HD;
+    const bf16_t* Ob = dO + (long)b * Tq * lddo + h * HD;
+
+    for (int q0 = 0; q0 < Tq; q0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qq = q0 + lr + 32 * i;
+            const bool ok = qq < Tq;
+            const bf16x8 a = ok ? *(const bf16x8*)(Qb + (long)qq * ldq + lc * 8) : zero8;
+            const bf16x8 g = ok ? *(const bf16x8*)(Ob + (long)qq * lddo + lc * 8) : zero8;
+            *(bf16x8*)&Qs[k_off(lr + 32 * i, lc)] = a;
+            *(bf16x8*)&Qt[v_off(lr + 32 * i, lc)] = a;
+            *(bf16x8*)&Os[k_off(lr + 32 * i, lc)] = g;
+            *(bf16x8*)&Ot[v_off(lr + 32 * i, lc)] = g;
+        }
+        if (t < 64) {
+            const int qq = q0 + t;
+            Ls[t] = (qq < Tq ? lse[bh * Tq + qq] : INFINITY) * LOG2E;
+            Ds[t] = qq < Tq ? Dsum[bh * Tq + qq] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sacc[i] = 0.f; pacc[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 qa = *(const bf16x8*)&Qs[k_off(32 * st + r, 2 * ks + hf)];
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
+                const bf16x8 ga = *(const bf16x8*)&Os[k_off(32 * st + r, 2 * ks + hf)];
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], pacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ql = 32 * st + (i & 3) + 8 * (i >> 2) + 4 * hf;
+                const float p = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[i], sc2, -Ls[ql]));
+                float pd = p, dp = pacc[i];
+                if (DROP) {
+                    const bool keep = avsr_attn_keep(seed, (uint64_t)bh * Tq + q0 + ql, tk4, key, pdrop);
+                    pd = keep ? p * keep_scale : 0.f;
+                    dp = keep ? dp * keep_scale : 0.f;
+                }
+                sacc[i] = pd;                                               // dropped P
+                pacc[i] = p * (dp - Ds[ql]) * scale;                        // dS
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = acc_to_bf16(sacc, s2), dsf = acc_to_bf16(pacc, s2);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr_frag(Ot, st, s2, db, lane), pf, dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr_frag(Qt, st, s2, db, lane), dsf, dk[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (kvalid) {
+        bf16_t* kp = dK + ((long)b * Tk + key) * lddk + h * HD;
+        bf16_t* vp = dV + ((long)b * Tk + key) * lddv + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 a, c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = (bf16_t)dk[db][4 * g + e]; c[e] = (bf16_t)dv[db][4 * g + e]; }
+                *(bf16x4*)(kp + 32 * db + 8 * g + 4 * hf) = a;
+                *(bf16x4*)(vp + 32 * db + 8 * g + 4 * hf) = c;
+            }
     }
 }
 
@@ -210,8 +474,8 @@ __global__ __launch_bounds__(256) void attn_fwd_valu_kernel(const T* __restrict_
             m[i] = mnew;
             l[i] = l[i] * alpha + wave_sum(p);
             if (pdrop > 0.f) {
-                const uint64_t idx = (((uint64_t)b * H + h) * Tq + qg) * (uint64_t)Tk + key;
-                p = (!dead && qg < Tq && avsr_keep(seed, idx, pdrop)) ? p * keep_scale : 0.f;
+                const uint64_t row = ((uint64_t)b * H + h) * Tq + qg;
+                p = (!dead && qg < Tq && avsr_attn_keep(seed, row, (Tk + 3) >> 2, key, pdrop)) ? p * keep_scale : 0.f;
             }
             float acc = o[i] * alpha;
 #pragma unroll 16
@@ -275,8 +539,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_valu_kernel(const T* __restri
             }
             const float p = dead ? 0.f : __expf(s * scale - L[i]);
             if (pdrop > 0.f) {
-                const uint64_t idx = (((uint64_t)b * H + h) * Tq + qg) * (uint64_t)Tk + key;
-                dp = (!dead && qg < Tq && avsr_keep(seed, idx, pdrop)) ? dp * keep_scale : 0.f;
+                const uint64_t row = ((uint64_t)b * H + h) * Tq + qg;
+                dp = (!dead && qg < Tq && avsr_attn_keep(seed, row, (Tk + 3) >> 2, key, pdrop)) ? dp * keep_scale : 0.f;
             }
             const float ds = p * (dp - Dr[i]) * scale;
             float acc = dq[i];
@@ -330,8 +594,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_valu_kernel(const T* __restr
             const float p = dead ? 0.f : __expf(s * scale - lse[((long)b * H + h) * Tq + qg]);
             float pd = p;
             if (pdrop > 0.f) {
-                const uint64_t idx = (((uint64_t)b * H + h) * Tq + qg) * (uint64_t)Tk + key;
-                const bool keep = !dead && avsr_keep(seed, idx, pdrop);
+                const uint64_t row = ((uint64_t)b * H + h) * Tq + qg;
+                const bool keep = !dead && avsr_attn_keep(seed, row, (Tk + 3) >> 2, key, pdrop);
                 pd = keep ? p * keep_scale : 0.f;
                 dp = keep ? dp * keep_scale : 0.f;
             }
@@ -374,13 +638,19 @@ extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, cons
     if (B > 65535 || H > 65535) return AVSR_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (use_mfma) {
-        if (dtype != AVSR_BF16 || p_drop > 0.f) return AVSR_EUNSUPPORTED;
+        if (dtype != AVSR_BF16) return AVSR_EUNSUPPORTED;
+        if (p_drop < 0.f || p_drop >= 1.f) return AVSR_EINVAL;
         if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return AVSR_EUNSUPPORTED;
         if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) % 16 || (uintptr_t)O % 8) return AVSR_EUNSUPPORTED;
         dim3 grid((unsigned)((Tq + 127) / 128), (unsigned)H, (unsigned)B);
-        hipLaunchKernelGGL(attn_fwd_mfma_kernel, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq, (const bf16_t*)K,
-                           (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse, (int)Tq, (int)Tk,
-                           (int)H, scale);
+        if (p_drop > 0.f)
+            hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
+                               (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
+                               (int)Tq, (int)Tk, (int)H, scale, p_drop, seed);
+        else
+            hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
+                               (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
+                               (int)Tq, (int)Tk, (int)H, scale, 0.f, seed);
         return avsr_launch_status();
     }
     dim3 grid((unsigned)((Tq + 31) / 32), (unsigned)H, (unsigned)B);
@@ -396,7 +666,7 @@ extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, cons
     return avsr_launch_status();
 }
 
-extern "C" int avsr_attn_bwd(avsr_stream_t stream, int dtype, const void* Q, int64_t ldq, const void* K, int64_t ldk,
+extern "C" int avsr_attn_bwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K, int64_t ldk,
                              const void* V, int64_t ldv, const void* O, int64_t ldo, const void* dO, int64_t lddo,
                              void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv,
                              const uint8_t* key_mask, const float* lse, float* d_ws, int64_t B, int64_t H, int64_t Tq,
@@ -405,6 +675,25 @@ extern "C" int avsr_attn_bwd(avsr_stream_t stream, int dtype, const void* Q, int
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return AVSR_EINVAL;
     if (head_dim != HD || B > 65535 || H > 65535) return AVSR_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    if (use_mfma) {
+        if (dtype != AVSR_BF16) return AVSR_EUNSUPPORTED;
+        if (p_drop < 0.f || p_drop >= 1.f) return AVSR_EINVAL;
+        if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 4 || lddk % 4 || lddv % 4) return AVSR_EUNSUPPORTED;
+        if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO) % 16 ||
+            ((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) % 8)
+            return AVSR_EUNSUPPORTED;
+        const dim3 g1((unsigned)((Tq + 127) / 128), (unsigned)H, (unsigned)B), g2((unsigned)((Tk + 127) / 128), (unsigned)H, (unsigned)B);
+#define RUN_MFMA(DROP)                                                                                                   \
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<DROP>, g1, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq, (const bf16_t*)K, \
+                       (long)ldk, (const bf16_t*)V, (long)ldv, (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, \
+                       (bf16_t*)dQ, (long)lddq, key_mask, lse, d_ws, (int)Tq, (int)Tk, (int)H, scale, p_drop, seed);        \
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<DROP>, g2, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq, (const bf16_t*)K, \
+                       (long)ldk, (const bf16_t*)V, (long)ldv, (const bf16_t*)dO, (long)lddo, (bf16_t*)dK, (long)lddk,       \
+                       (bf16_t*)dV, (long)lddv, key_mask, lse, d_ws, (int)Tq, (int)Tk, (int)H, scale, p_drop, seed)
+        if (p_drop > 0.f) { RUN_MFMA(true); } else { RUN_MFMA(false); }
+#undef RUN_MFMA
+        return avsr_launch_status();
+    }
     dim3 gq((unsigned)((Tq + 31) / 32), (unsigned)H, (unsigned)B), gk((unsigned)((Tk + 63) / 64), (unsigned)H, (unsigned)B);
 #define RUN(T)                                                                                                          \
     hipLaunchKernelGGL(attn_bwd_dq_valu_kernel<T>, gq, dim3(256), 0, s, (const T*)Q, (long)ldq, (const T*)K, (long)ldk, \

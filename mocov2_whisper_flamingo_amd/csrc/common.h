@@ -77,7 +77,7 @@ template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return
 __host__ __device__ __forceinline__ uint32_t avsr_mulhi32(uint32_t a, uint32_t b) {
     return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
 }
-__host__ __device__ __forceinline__ uint32_t avsr_philox(uint64_t seed, uint64_t idx) {
+__host__ __device__ __forceinline__ void avsr_philox4(uint64_t seed, uint64_t idx, uint32_t out[4]) {
     uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -87,10 +87,28 @@ __host__ __device__ __forceinline__ uint32_t avsr_philox(uint64_t seed, uint64_t
         c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return c0;
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__host__ __device__ __forceinline__ uint32_t avsr_philox(uint64_t seed, uint64_t idx) {
+    uint32_t o[4];
+    avsr_philox4(seed, idx, o);
+    return o[0];
+}
+__host__ __device__ __forceinline__ bool avsr_bits_keep(uint32_t bits, float p) {
+    return (float)(bits >> 8) * (1.0f / 16777216.0f) >= p;
 }
 // keep-decision for dropout probability p: keep iff u >= p, u uniform in [0,1)
 __host__ __device__ __forceinline__ bool avsr_keep(uint64_t seed, uint64_t idx, float p) {
-    const float u = (float)(avsr_philox(seed, idx) >> 8) * (1.0f / 16777216.0f);
-    return u >= p;
+    return avsr_bits_keep(avsr_philox(seed, idx), p);
+}
+// Dropout of attention probabilities.  Element (row, key) of a [rows, Tk] matrix
+// (row = (b*H + h)*Tq + q) draws output (key & 3) of counter row*tk4 + key/4 with
+// tk4 = ceil(Tk/4): one generator call covers four neighbouring keys.
+__host__ __device__ __forceinline__ uint64_t avsr_attn_counter(uint64_t row, int tk4, int key) {
+    return row * (uint64_t)tk4 + (uint64_t)(key >> 2);
+}
+__host__ __device__ __forceinline__ bool avsr_attn_keep(uint64_t seed, uint64_t row, int tk4, int key, float p) {
+    uint32_t o[4];
+    avsr_philox4(seed, avsr_attn_counter(row, tk4, key), o);
+    return avsr_bits_keep(o[key & 3], p);
 }

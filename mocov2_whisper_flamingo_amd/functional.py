@@ -145,7 +145,9 @@ class AttnFn(Function):
 
     @staticmethod
     def forward(ctx, q, k, v, key_mask, H, scale, p_drop, seed):
-        o, lse = ops.attn_fwd(q, k, v, H, key_mask=key_mask, scale=scale, save_lse=True, p_drop=p_drop, seed=seed)
+        mfma = q.dtype == torch.bfloat16                    # bf16: MFMA flash kernels; fp32: exact fp32-math kernels
+        o, lse = ops.attn_fwd(q, k, v, H, key_mask=key_mask, scale=scale, use_mfma=mfma, save_lse=True, p_drop=p_drop,
+                              seed=seed)
         ctx.save_for_backward(q, k, v, o, lse, key_mask)
         ctx.cfg = (H, scale, p_drop, seed)
         return o
@@ -154,7 +156,8 @@ class AttnFn(Function):
     def backward(ctx, do):
         q, k, v, o, lse, key_mask = ctx.saved_tensors
         H, scale, p_drop, seed = ctx.cfg
-        dq, dk, dv = ops.attn_bwd(q, k, v, o, do, lse, H, key_mask=key_mask, scale=scale, p_drop=p_drop, seed=seed)
+        dq, dk, dv = ops.attn_bwd(q, k, v, o, do, lse, H, key_mask=key_mask, scale=scale,
+                                  use_mfma=q.dtype == torch.bfloat16, p_drop=p_drop, seed=seed)
         return dq, dk, dv, None, None, None, None, None
 
 

@@ -197,7 +197,7 @@ def attn_fwd(q, k, v, H, *, key_mask=None, scale=1.0, use_mfma=False, save_lse=F
     return (o, lse) if save_lse else o
 
 
-def attn_bwd(q, k, v, o, do, lse, H, *, key_mask=None, scale=1.0, p_drop=0.0, seed=0):
+def attn_bwd(q, k, v, o, do, lse, H, *, key_mask=None, scale=1.0, use_mfma=False, p_drop=0.0, seed=0):
     lib = _lib.load()
     B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
     dq = torch.empty((B, Tq, H * 64), dtype=q.dtype, device=q.device)
@@ -205,7 +205,7 @@ def attn_bwd(q, k, v, o, do, lse, H, *, key_mask=None, scale=1.0, p_drop=0.0, se
     dv = torch.empty((B, Tk, H * 64), dtype=q.dtype, device=q.device)
     ws = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
     do = do.contiguous()
-    check(lib.avsr_attn_bwd(_stream(), _dt(q), q.data_ptr(), _bthd(q, H), k.data_ptr(), _bthd(k, H), v.data_ptr(),
+    check(lib.avsr_attn_bwd(_stream(), _dt(q), int(use_mfma), q.data_ptr(), _bthd(q, H), k.data_ptr(), _bthd(k, H), v.data_ptr(),
                             _bthd(v, H), o.data_ptr(), _bthd(o, H), do.data_ptr(), _bthd(do, H), dq.data_ptr(), H * 64,
                             dk.data_ptr(), H * 64, dv.data_ptr(), H * 64, _p(key_mask), lse.data_ptr(), ws.data_ptr(),
                             B, H, Tq, Tk, 64, scale, p_drop, seed), "avsr_attn_bwd")

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 import oracle  # noqa: E402  (the checker)
 from mocov2_whisper_flamingo_amd import ops  # noqa: E402
-from tests.philox_ref import keep_mask  # noqa: E402
+from tests.philox_ref import attn_keep_mask, keep_mask  # noqa: E402
 
 
 def rel_err(got, ref):
@@ -189,7 +189,7 @@ def test_attn_valu_fwd_bwd(dev, dtype, p):
     mask = torch.zeros(B, Tk, dtype=torch.uint8)
     mask[0, 50:] = 1
     seed = 0x1234ABCD5678
-    keep = torch.from_numpy(keep_mask(seed, (B, H, Tq, Tk), p)).float() if p > 0 else None
+    keep = torch.from_numpy(attn_keep_mask(seed, (B, H, Tq, Tk), p)).float() if p > 0 else None
     qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
     ref = _attn_ref(qr, kr, vr, H, mask, 0.125, keep, p)
     do = rnd(g, B, Tq, H * 64, dtype=dtype)
@@ -202,6 +202,47 @@ def test_attn_valu_fwd_bwd(dev, dtype, p):
     assert rel_err(dq, qr.grad) < tol(dtype) * 2
     assert rel_err(dk, kr.grad) < tol(dtype) * 2
     assert rel_err(dv, vr.grad) < tol(dtype) * 2
+
+
+@pytest.mark.parametrize("p", [0.0, 0.25])
+@pytest.mark.parametrize("B,H,Tq,Tk,masked", [(2, 2, 75, 70, True), (1, 3, 200, 333, True), (2, 8, 75, 75, False),
+                                              (1, 1, 129, 64, True)])
+def test_attn_mfma_fwd_bwd(dev, p, B, H, Tq, Tk, masked):
+    """bf16 MFMA forward + backward with key mask and replayed dropout against the fp32 computation on the
+    bf16-rounded operands; one batch row has every key masked (output and gradients must be zero there)."""
+    g = torch.Generator().manual_seed(17 + Tq)
+    dtype = torch.bfloat16
+    q, k, v = (rnd(g, B, t, H * 64, dtype=dtype) for t in (Tq, Tk, Tk))
+    mask = torch.zeros(B, Tk, dtype=torch.uint8)
+    if masked:
+        mask[0, Tk // 2:] = 1
+        mask[0, 3] = 1
+        if B > 1:
+            mask[1, :] = 1
+    seed = 0x9E3779B97F4A7C15
+    keep = torch.from_numpy(attn_keep_mask(seed, (B, H, Tq, Tk), p)).float() if p > 0 else None
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, H, mask, 0.125, keep, p)
+    do = rnd(g, B, Tq, H * 64, dtype=dtype)
+    ref.backward(do)
+    qd, kd, vd = (t.to(dev, dtype) for t in (q, k, v))
+    md = mask.to(dev) if masked else None
+    o, lse = ops.attn_fwd(qd, kd, vd, H, key_mask=md, scale=0.125, use_mfma=True, save_lse=True, p_drop=p, seed=seed)
+    assert torch.isfinite(o.float()).all()
+    assert rel_err(o, ref) < 2e-2
+    dq, dk, dv = ops.attn_bwd(qd, kd, vd, o, do.to(dev, dtype), lse, H, key_mask=md, scale=0.125, use_mfma=True,
+                              p_drop=p, seed=seed)
+    for got, want in ((dq, qr.grad), (dk, kr.grad), (dv, vr.grad)):
+        assert torch.isfinite(got.float()).all()
+        assert rel_err(got, want) < 3e-2
+    if masked and B > 1:
+        assert float(o[1].float().abs().max()) == 0.0 and float(dq[1].float().abs().max()) == 0.0
+        assert float(dk[1].float().abs().max()) == 0.0 and float(dv[1].float().abs().max()) == 0.0
+    # the MFMA and the fp32-math kernels draw the same dropout mask
+    o2, lse2 = ops.attn_fwd(qd, kd, vd, H, key_mask=md, scale=0.125, use_mfma=False, save_lse=True, p_drop=p, seed=seed)
+    assert rel_err(o, o2) < 2e-2
+    fin = torch.isfinite(lse2)
+    assert torch.equal(fin, torch.isfinite(lse)) and (lse[fin] - lse2[fin]).abs().max() < 2e-2
 
 
 @pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
