@@ -58,6 +58,18 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
+// gelu via the Abramowitz-Stegun 7.1.26 erfc polynomial (|error| <= 1.5e-7 on erf): branch-free, one rcp and
+// one exp2 - for epilogues whose result is rounded to bf16 anyway
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(t, poly, 1.421413741f);
+    poly = fmaf(t, poly, -0.284496736f);
+    poly = fmaf(t, poly, 0.254829592f);
+    const float q = 0.5f * poly * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // erfc(z) / 2
+    return x * (x < 0.f ? q : 1.0f - q);
+}
 // d/dx of gelu_erf
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

@@ -143,9 +143,16 @@ __device__ __forceinline__ void stats_quad(const GemmP& p, f32x4 s, f32x4 s2, in
 // thread, residual reads and output stores are 16-byte (bf16) or 2 x 16-byte (fp32) and a row
 // segment of the tile is written by consecutive lanes.  Column statistics are reduced per block
 // and stored into row `tm` of the [tiles_m, N] slabs.
-template <int BN_, typename OutT>
-__device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[4][BN_ / 32], char* lds, int m0, int n0,
-                                              int tm, long cbase, int lane, int wave) {
+// The activation is a template parameter of the body (a run-time `act` test inside the per-element loop
+// costs several scalar branches per element) and the row loop is NOT unrolled: the epilogue runs once per
+// tile, so its instructions are fetched cold, and straight-line code four times as long measured 17-30 %
+// slower on the K = 768 encoder GEMMs (instruction-cache misses, not arithmetic).
+#ifndef G_EPI_UNROLL_CONV
+#define G_EPI_UNROLL_CONV 1
+#endif
+template <int BN_, typename OutT, int ACT, bool CONV>
+__device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[4][BN_ / 32], char* lds, const float* sb,
+                                              int m0, int n0, int tm, long cbase, int lane, int wave) {
     constexpr int NJ = BN_ / 32, LDT = BN_ + 4, CG = BN_ / 8, RS = 256 / CG;
     float* Ct = (float*)lds;
     float* red = Ct + 64 * LDT;                 // [4][2][BN_] per-wave column partials
@@ -155,15 +162,17 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[4][BN
     const int n = n0 + cg * 8;
     const float g = p.gate ? tanhf(*p.gate) : 1.0f;
     float sc[8], bi[8], s1[8], s2[8];
+    {                                           // alpha * scale and bias of this thread's 8 columns, staged at kernel entry
+        const f32x4 a0 = *(const f32x4*)(sb + cg * 8), a1 = *(const f32x4*)(sb + cg * 8 + 4);
+        const f32x4 b0 = *(const f32x4*)(sb + BN_ + cg * 8), b1 = *(const f32x4*)(sb + BN_ + cg * 8 + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const bool in = n + e < p.N;
-        sc[e] = (p.scale && in) ? p.scale[n + e] : 1.f;
-        bi[e] = (p.bias && in) ? p.bias[n + e] : 0.f;
-        s1[e] = 0.f; s2[e] = 0.f;
+        for (int e = 0; e < 4; ++e) { sc[e] = a0[e]; sc[4 + e] = a1[e]; bi[e] = b0[e]; bi[4 + e] = b1[e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     }
-    const bool post_relu = p.act == AVSR_ACT_RELU_AFTER_RESIDUAL;
     const bool full = p.vec_ok && n + 7 < p.N;
+    const bool has_res = p.res != nullptr;
+    const bool stats = p.csum != nullptr;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
@@ -173,34 +182,36 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[4][BN
             for (int j = 0; j < NJ; ++j)
                 *(f32x4*)&Ct[(wm * 32 + ii * 16 + (lane & 15)) * LDT + (wn * NJ + j) * 16 + (lane >> 4) * 4] = acc[2 * h + ii][j];
         __syncthreads();
-        for (int lr = r0; lr < 64; lr += RS) {
+#pragma unroll((CONV && G_EPI_UNROLL_CONV) ? 64 / RS : 1)
+        for (int it = 0; it < 64 / RS; ++it) {
+            const int lr = r0 + it * RS;
             const int m = m0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
             if (m >= p.M) continue;
             const f32x4 c0 = *(const f32x4*)&Ct[lr * LDT + cg * 8], c1 = *(const f32x4*)&Ct[lr * LDT + cg * 8 + 4];
             float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float x = v[e] * p.alpha * sc[e] + bi[e];
-                s1[e] += x; s2[e] += x * x;
-                if (p.act == AVSR_ACT_GELU) x = gelu_erf(x);
-                else if (p.act == AVSR_ACT_RELU) x = fmaxf(x, 0.f);
+                float x = fmaf(v[e], sc[e], bi[e]);
+                if (stats) { s1[e] += x; s2[e] = fmaf(x, x, s2[e]); }
+                if (ACT == AVSR_ACT_GELU) x = gelu_erf_fast(x);
+                else if (ACT == AVSR_ACT_RELU) x = fmaxf(x, 0.f);
                 v[e] = x;
             }
             OutT* cp = (OutT*)p.C + cbase + (long)m * p.ldc + n;
-            const OutT* rp = p.res ? (const OutT*)p.res + (long)(p.res_period > 0 ? m % p.res_period : m) * p.ldr + n : nullptr;
+            const OutT* rp = has_res ? (const OutT*)p.res + (long)(p.res_period > 0 ? m % p.res_period : m) * p.ldr + n : nullptr;
             if (full) {
-                if (rp) {
+                if (has_res) {
                     if constexpr (sizeof(OutT) == 4) {
                         const f32x4 ra = *(const f32x4*)rp, rb = *(const f32x4*)(rp + 4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] = ra[e] + g * v[e]; v[4 + e] = rb[e] + g * v[4 + e]; }
+                        for (int e = 0; e < 4; ++e) { v[e] = fmaf(g, v[e], ra[e]); v[4 + e] = fmaf(g, v[4 + e], rb[e]); }
                     } else {
                         const bf16x8 rv = *(const bf16x8*)rp;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (float)rv[e] + g * v[e];
+                        for (int e = 0; e < 8; ++e) v[e] = fmaf(g, v[e], (float)rv[e]);
                     }
                 }
-                if (post_relu) {
+                if (ACT == AVSR_ACT_RELU_AFTER_RESIDUAL) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
@@ -218,15 +229,15 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[4][BN
                 for (int e = 0; e < 8; ++e) {
                     if (n + e < p.N) {
                         float x = v[e];
-                        if (rp) x = to_f32<OutT>(rp[e]) + g * x;
-                        if (post_relu) x = fmaxf(x, 0.f);
+                        if (has_res) x = fmaf(g, x, to_f32<OutT>(rp[e]));
+                        if (ACT == AVSR_ACT_RELU_AFTER_RESIDUAL) x = fmaxf(x, 0.f);
                         cp[e] = from_f32<OutT>(x);
                     }
                 }
             }
         }
     }
-    if (p.csum) {
+    if (stats) {
         // lanes with equal (lane % CG) own the same columns: fold them, then the 4 waves through LDS
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -251,6 +262,18 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[4][BN
     }
 }
 
+template <int BN_, typename OutT, bool CONV>
+__device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[4][BN_ / 32], char* lds, const float* sb,
+                                              int m0, int n0, int tm, long cbase, int lane, int wave) {
+    switch (p.act) {                            // block-uniform
+        case AVSR_ACT_GELU: epilogue_body<BN_, OutT, AVSR_ACT_GELU, CONV>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
+        case AVSR_ACT_RELU: epilogue_body<BN_, OutT, AVSR_ACT_RELU, CONV>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
+        case AVSR_ACT_RELU_AFTER_RESIDUAL:
+            epilogue_body<BN_, OutT, AVSR_ACT_RELU_AFTER_RESIDUAL, CONV>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
+        default: epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
+    }
+}
+
 // ---------------------------------------------------------------- bf16 ----
 // 128 x BN x 64 tiles, 4 waves, v_mfma_f32_16x16x32_bf16.  Operand tiles go
 // global -> LDS directly (global_load_lds_dwordx4): one wave instruction moves
@@ -270,8 +293,13 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[4][BN
 //   NST = 1: one 32-KiB stage, two barriers per K-step, 4 workgroups per CU - latency is hidden by
 //            the other resident workgroups; fastest whenever the grid can fill the chip (about 500 tiles or more).
 //   NST = 2: double-buffered, 2 workgroups per CU - better when there are too few tiles for that.
+//   NST = 4: grids of at most one workgroup per CU (the small GEMMs of the trainable tail): nothing else hides
+//            the ~1300-cycle DMA latency there, so three K-steps stay in flight (0.55 -> 0.25 us per K-step).
 #ifndef G_NST_SWITCH_TILES
 #define G_NST_SWITCH_TILES 500
+#endif
+#ifndef G_DEEP_TILES
+#define G_DEEP_TILES 256
 #endif
 
 __device__ __attribute__((aligned(16))) unsigned int avsr_zero_page[4] = {0u, 0u, 0u, 0u};
@@ -288,10 +316,21 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "unsupported wait count");
 }
 
+// Build with -DGEMM_STAMPS (scripts/build_variants.sh) to record 100-MHz timestamps of workgroup 0's phases.
+#ifdef GEMM_STAMPS
+__device__ unsigned long long avsr_stamps[16];
+extern "C" int avsr_debug_read_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(avsr_stamps), sizeof(avsr_stamps)) == hipSuccess ? 0 : -3;
+}
+#define STAMP(i) do { stamp[i] = wall_clock64(); cyc[i] = clock64(); } while (0)
+#else
+#define STAMP(i)
+#endif
+
 template <int BN_, int G_NST> constexpr int gemm_lds_bytes() {
     constexpr int stage = (G_BM / 8 + BN_ / 8) * 1024;
     constexpr int epi = (64 * (BN_ + 4) + 8 * BN_) * 4;
-    return G_NST * stage > epi ? G_NST * stage : epi;
+    return (G_NST * stage > epi ? G_NST * stage : epi) + 2 * BN_ * 4;     // + the tile's scale / bias columns
 }
 
 template <int BN_, int G_NST, bool CONV, typename OutT>
@@ -302,6 +341,10 @@ __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(Ge
     constexpr int NAL = APIECES / 4, NBL = BPIECES / 4;       // pieces each wave loads per K-step
     constexpr int LPT = NAL + NBL;          // DMA instructions per wave per K-step
     extern __shared__ __attribute__((aligned(16))) char lds[];
+#ifdef GEMM_STAMPS
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    STAMP(0);
 
     int tm, tn;
     tile_coords(p, tm, tn);
@@ -313,6 +356,14 @@ __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(Ge
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+
+    // alpha * scale[n] and bias[n] of the tile's columns go to LDS now, so the epilogue does not wait on them
+    float* sb = (float*)(lds + gemm_lds_bytes<BN_, G_NST>() - 2 * BN_ * 4);
+    if (t < BN_) {
+        const int nc = min(n0 + t, p.N - 1);
+        sb[t] = p.scale ? p.scale[nc] * p.alpha : p.alpha;
+        sb[BN_ + t] = p.bias ? p.bias[nc] : 0.f;
+    }
 
     // ---- per-lane DMA sources -------------------------------------------------
     // Piece q of this wave covers rows 8*(4*wave+q) .. +7; lane i fetches row i>>3, source chunk
@@ -420,12 +471,16 @@ __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(Ge
         }
     };
 
+    STAMP(1);
     if constexpr (G_NST == 1) {
         for (int kt = 0; kt < nk; ++kt) {
             __builtin_amdgcn_s_barrier();       // the previous step is fully read
             issue(kt);
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();       // every wave's pieces have landed
+#ifdef GEMM_STAMPS
+            if (kt == 0) STAMP(2);
+#endif
             compute(lds, kt);
         }
     } else {
@@ -434,11 +489,29 @@ __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(Ge
         for (int kt = 0; kt < nk; ++kt) {
             wait_vmcnt<LPT * (G_NST - 2)>();    // step kt has landed for this wave ...
             __builtin_amdgcn_s_barrier();       // ... and for every wave; step kt-1 is fully read
+#ifdef GEMM_STAMPS
+            if (kt == 0) STAMP(2);
+#endif
             compute(lds + (kt % G_NST) * STAGE_BYTES, kt);
         }
         wait_vmcnt<0>();                        // drain the re-loaded steps before the LDS is reused
     }
-    epilogue_tile<BN_, OutT>(p, acc, lds, m0, n0, tm, cbase, lane, wave);
+    STAMP(3);
+    epilogue_tile<BN_, OutT, CONV>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+#ifdef GEMM_STAMPS
+    STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(5);
+#ifdef GEMM_STAMPS_TWICE
+    __syncthreads();
+    epilogue_tile<BN_, OutT, CONV>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+    STAMP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(7);
+#endif
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && t == 0)
+        for (int i = 0; i < 8; ++i) { avsr_stamps[i] = stamp[i]; avsr_stamps[8 + i] = cyc[i]; }
+#endif
 }
 
 // ----------------------------------------------------------------- f32 ----
@@ -602,7 +675,9 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     } while (0)
     if (bf) {
         const bool single = ntiles * g->batch >= G_NST_SWITCH_TILES;
-        if (bn == 64) { if (single) LAUNCH_CV_OT(64, 1); else LAUNCH_CV_OT(64, 2); }
+        if (!conv && bn == 128 && ntiles * g->batch <= G_DEEP_TILES) {     // at most one workgroup per CU: 3 K-steps in flight
+            if (of) LAUNCHB(128, 4, false, float); else LAUNCHB(128, 4, false, bf16_t);
+        } else if (bn == 64) { if (single) LAUNCH_CV_OT(64, 1); else LAUNCH_CV_OT(64, 2); }
         else          { if (single) LAUNCH_CV_OT(128, 1); else LAUNCH_CV_OT(128, 2); }
     } else {
         if (conv) { if (of) LAUNCH(gemm_f32_kernel, true, float); else LAUNCH(gemm_f32_kernel, true, bf16_t); }

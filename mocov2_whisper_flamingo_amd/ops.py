@@ -98,7 +98,8 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
     e0.record()
     check(lib.avsr_gemm_nt(_stream(), ctypes.byref(d)), "avsr_gemm_nt")
     e1.record()
-    GEMM_PROFILE.append((e0, e1, 2.0 * Mv * N * K * batch, "bf16" if a.dtype == torch.bfloat16 else "f32"))
+    GEMM_PROFILE.append((e0, e1, 2.0 * Mv * N * K * batch, "bf16" if a.dtype == torch.bfloat16 else "f32",
+                         (Mv, N, K, batch, None if conv is None else tuple(conv))))
     return out
 
 

@@ -31,10 +31,19 @@ def desc(a, b, out, conv=None):
 cases = []
 for name, M, N, K, odt in [("qkv", 12000, 2304, 768, torch.bfloat16), ("out", 12000, 768, 768, torch.float32),
                            ("fc1", 12000, 3072, 768, torch.bfloat16), ("fc2", 12000, 768, 3072, torch.float32),
-                           ("4096^3", 4096, 4096, 4096, torch.bfloat16)]:
+                           ("4096^3", 4096, 4096, 4096, torch.bfloat16), ("tiny", 128, 128, 64, torch.bfloat16),
+                           ("t512", 600, 512, 512, torch.bfloat16), ("t2048", 600, 512, 2048, torch.float32),
+                           ("dW", 512, 2048, 600, torch.float32)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16); b = torch.randn(N, K, device=dev).to(torch.bfloat16)
     out = torch.empty(M, N, device=dev, dtype=odt)
     cases.append((name, desc(a, b, out), 2.0 * M * N * K, (a, b, out)))
+    if M == 12000:                      # the same product with the epilogue the encoder uses
+        bias = torch.randn(N, device=dev)
+        d = desc(a, b, out)
+        d.bias = bias.data_ptr()
+        if name == "fc1": d.act = 1
+        if odt == torch.float32: d.residual, d.ldr = out.data_ptr(), out.stride(0)
+        cases.append((name + "+e", d, 2.0 * M * N * K, (a, b, out, bias)))
 for name, n, H, C, Co, k, s in [("l1.c2", 600, 25, 64, 64, 3, 1), ("l1.c3", 600, 25, 64, 256, 1, 1), ("l2.c2", 600, 13, 128, 128, 3, 1),
                                 ("l3.c1", 600, 7, 1024, 256, 1, 1), ("l3.c2", 600, 7, 256, 256, 3, 1), ("l4.c2", 600, 4, 512, 512, 3, 1)]:
     pad = 1 if k == 3 else 0
@@ -42,6 +51,10 @@ for name, n, H, C, Co, k, s in [("l1.c2", 600, 25, 64, 64, 3, 1), ("l1.c3", 600,
     x = torch.randn(n, H, H, C, device=dev).to(torch.bfloat16); w = (torch.randn(Co, k * k * C, device=dev) * 0.05).to(torch.bfloat16)
     out = torch.empty(n * OH * OH, Co, device=dev, dtype=torch.bfloat16)
     cases.append((name, desc(x, w, out, (H, C, k, s, pad, OH)), 2.0 * n * OH * OH * Co * k * k * C, (x, w, out)))
+    slab = torch.zeros(2, (n * OH * OH + 127) // 128, Co, device=dev)
+    d = desc(x, w, out, (H, C, k, s, pad, OH))
+    d.col_sum, d.col_sumsq = slab[0].data_ptr(), slab[1].data_ptr()
+    cases.append((name + "+s", d, 2.0 * n * OH * OH * Co * k * k * C, (x, w, out, slab)))
 
 stream = torch.cuda.current_stream().cuda_stream
 ROUNDS, REP = 7, 10

@@ -6,6 +6,6 @@ make -j8 >/dev/null
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags -c gemm.hip -o /tmp/gemm_$name.o
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../scripts/variants/libavsr_$name.so /tmp/gemm_$name.o attention.o norm.o visual.o loss.o elementwise.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../scripts/variants/libavsr_$name.so /tmp/gemm_$name.o attention.o norm.o visual.o loss.o elementwise.o logmel.o
   echo built $name "$flags"
 done
