@@ -163,7 +163,10 @@ int avsr_logmel_fwd(avsr_stream_t stream, int variant, int out_dtype, const floa
  * Visual frontend pieces (models/moco_visual_frontend.py).
  * avsr_stem3d_fwd: Conv3d(3,64,(5,3,3),s(1,2,2),p(2,3,3),bias=False) (:15) on
  *   video [B,T,3,H,W] fp32 -> NHWC [B*T,OH,OW,64]; weight_packed is the
- *   weight transposed to [135 taps][64].  With scale/shift the eval-mode
+ *   weight transposed to [135 taps][64]; weight_frags (optional) is its bf16
+ *   fragment copy from avsr_stem3d_pack_frags: when given with a bf16 output
+ *   the convolution runs as an implicit GEMM on MFMA over a bf16 copy of the
+ *   input window, otherwise as a direct fp32 convolution.  With scale/shift the eval-mode
  *   BatchNorm3d + ReLU (:16-17) are folded in; otherwise the raw convolution
  *   is stored and per-workgroup channel sums / sums of squares go to the
  *   [avsr_stem3d_stats_parts(), 64] slabs (training-mode batch statistics).
@@ -175,9 +178,12 @@ int avsr_logmel_fwd(avsr_stream_t stream, int variant, int out_dtype, const floa
  *   running-stat update with the unbiased variance) and eval mode (fold).
  * ---------------------------------------------------------------------- */
 int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float* video, const float* weight_packed,
-                    void* out, const float* scale, const float* shift, float* col_sum, float* col_sumsq,
-                    int64_t B, int64_t T, int64_t H, int64_t W);
+                    const void* weight_frags, void* out, const float* scale, const float* shift, float* col_sum,
+                    float* col_sumsq, int64_t B, int64_t T, int64_t H, int64_t W);
 int64_t avsr_stem3d_stats_parts(int64_t B, int64_t T, int64_t H, int64_t W);
+/* bf16 MFMA-fragment copy of the stem weight (avsr_stem3d_frag_elems() bf16 values) from weight_packed */
+int64_t avsr_stem3d_frag_elems(void);
+int avsr_stem3d_pack_frags(avsr_stream_t stream, const float* weight_packed, void* weight_frags);
 int avsr_maxpool3x3s2(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y,
                       const float* scale, const float* shift, int64_t N, int64_t H, int64_t W, int64_t C);
 int avsr_avgpool_mask_fwd(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y,

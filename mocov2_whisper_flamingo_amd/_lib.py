@@ -47,7 +47,9 @@ SIGNATURES = {
     "avsr_logmel_tables": (_i32, [_vp, _i32, _vp, _vp]),
     "avsr_logmel_workspace_floats": (_i64, [_i64, _i64]),
     "avsr_logmel_fwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
-    "avsr_stem3d_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
+    "avsr_stem3d_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
+    "avsr_stem3d_frag_elems": (_i64, []),
+    "avsr_stem3d_pack_frags": (_i32, [_vp, _vp, _vp]),
     "avsr_maxpool3x3s2": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
     "avsr_avgpool_mask_fwd": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
     "avsr_bn_finalize": (_i32, [_vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp]),

@@ -147,9 +147,6 @@ __device__ __forceinline__ void stats_quad(const GemmP& p, f32x4 s, f32x4 s2, in
 // costs several scalar branches per element) and the row loop is NOT unrolled: the epilogue runs once per
 // tile, so its instructions are fetched cold, and straight-line code four times as long measured 17-30 %
 // slower on the K = 768 encoder GEMMs (instruction-cache misses, not arithmetic).
-#ifndef G_EPI_UNROLL_CONV
-#define G_EPI_UNROLL_CONV 1
-#endif
 template <int BN_, typename OutT, int ACT, bool CONV>
 __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[4][BN_ / 32], char* lds, const float* sb,
                                               int m0, int n0, int tm, long cbase, int lane, int wave) {
@@ -182,7 +179,7 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[4][BN
             for (int j = 0; j < NJ; ++j)
                 *(f32x4*)&Ct[(wm * 32 + ii * 16 + (lane & 15)) * LDT + (wn * NJ + j) * 16 + (lane >> 4) * 4] = acc[2 * h + ii][j];
         __syncthreads();
-#pragma unroll((CONV && G_EPI_UNROLL_CONV) ? 64 / RS : 1)
+#pragma unroll 1
         for (int it = 0; it < 64 / RS; ++it) {
             const int lr = r0 + it * RS;
             const int m = m0 + (lr >> 5) * 64 + h * 32 + (lr & 31);

@@ -26,7 +26,8 @@ template <typename TO>
 __global__ __launch_bounds__(256) void stem3d_kernel(const float* __restrict__ video, const float* __restrict__ wpacked,
                                                      TO* __restrict__ out, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, float* __restrict__ csum,
-                                                     float* __restrict__ csq, int T, int H, int W, int OH, int OW) {
+                                                     float* __restrict__ csq, int T, int H, int W, int OH, int OW,
+                                                     int parts_per_frame) {
     __shared__ __attribute__((aligned(16))) float ws[ST_TAPS * ST_CO];
     for (int i = threadIdx.x; i < ST_TAPS * ST_CO / 4; i += 256) ((f32x4*)ws)[i] = ((const f32x4*)wpacked)[i];
     __syncthreads();
@@ -92,12 +93,166 @@ __global__ __launch_bounds__(256) void stem3d_kernel(const float* __restrict__ v
         }
     }
     if (csum) {
-        const long part = (long)frame * gridDim.x + blockIdx.x;
+        const long part = (long)frame * parts_per_frame + blockIdx.x;
 #pragma unroll
         for (int c = 0; c < ST_CPW; ++c) {
             const float s = wave_sum(st1[c]), s2 = wave_sum(st2[c]);
             if (lane == 0) { csum[part * ST_CO + c0 + c] = s; csq[part * ST_CO + c0 + c] = s2; }
         }
+        if (blockIdx.x == 0)                          // slab rows of this frame no workgroup owns
+            for (int i = threadIdx.x; i < (parts_per_frame - (int)gridDim.x) * ST_CO; i += 256) {
+                csum[((long)frame * parts_per_frame + gridDim.x) * ST_CO + i] = 0.f;
+                csq[((long)frame * parts_per_frame + gridDim.x) * ST_CO + i] = 0.f;
+            }
+    }
+}
+
+// ---- MFMA form of the stem (bf16 output) --------------------------------------
+// The same convolution as an implicit GEMM on v_mfma_f32_16x16x32_bf16: rows = output pixels,
+// columns = 64 output channels, K = (kt, ci, kh, kw') with kw' padded 3 -> 4 (zero weight), 180 -> 192.
+// A workgroup owns `rows` output rows of one frame: the (2*rows+1) x (W+8) input window of the 5 x 3
+// (frame, channel) planes is converted to bf16 and staged in LDS once with its zero padding, so the
+// gather needs no bounds tests: a lane's 8 consecutive k are two window rows x 4 consecutive columns,
+// i.e. four aligned ds_read_b32.  The whole weight matrix lives in registers as 24 pre-packed
+// fragments (avsr_stem3d_pack_frags); each wave walks 16-pixel tiles and keeps 4 accumulator tiles.
+#define SM_KS 6                         // K-steps of 32
+#define SM_ROWIDS 45                    // real (kt, ci, kh) rows; ids 45..47 carry zero weights
+#define SM_FRAG_ELEMS (SM_KS * 4 * 64 * 8)
+
+__global__ void stem3d_pack_frags_kernel(const float* __restrict__ wpacked, bf16_t* __restrict__ frags) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= SM_FRAG_ELEMS) return;
+    const int j = i & 7, lane = (i >> 3) & 63, ct = (i >> 9) & 3, ks = i >> 11;
+    const int cout = 16 * ct + (lane & 15);
+    const int k = 32 * ks + 8 * (lane >> 4) + j;
+    const int rowid = k >> 2, kw = k & 3;
+    float v = 0.f;
+    if (rowid < SM_ROWIDS && kw < 3) {
+        const int kh = rowid % 3, pl = rowid / 3, ci = pl % 3, kt = pl / 3;
+        v = wpacked[((((ci * ST_KT + kt) * ST_KH + kh) * ST_KW) + kw) * ST_CO + cout];
+    }
+    frags[i] = (bf16_t)v;
+}
+
+__global__ __launch_bounds__(256) void stem3d_mfma_kernel(const float* __restrict__ video, const bf16_t* __restrict__ frags,
+                                                         bf16_t* __restrict__ out, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ csum,
+                                                         float* __restrict__ csq, int T, int H, int W, int OH, int OW,
+                                                         int rows, int parts_per_frame) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* win = (bf16_t*)smem;                     // [15 planes][2*rows+1][PW]
+    const int PW = W + 8, WR = 2 * rows + 1;
+    float* red = (float*)(smem + (size_t)15 * WR * PW * sizeof(bf16_t));   // [4 waves][2][64]
+    const int frame = blockIdx.y, b = frame / T, t = frame - b * T;
+    const int oh0 = blockIdx.x * rows;
+    const int nrow = min(rows, OH - oh0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- stage the window: pairs of columns, zero outside the image / the clip ----
+    const int PP = PW >> 1;
+    for (int i = tid; i < 15 * WR * PP; i += 256) {
+        const int cp = i % PP, rr = (i / PP) % WR, pl = i / (PP * WR);
+        const int ci = pl % 3, tt = t + pl / 3 - 2;
+        const int ih = 2 * oh0 - 3 + rr, iw = 2 * cp - 3;
+        float x0 = 0.f, x1 = 0.f;
+        if (tt >= 0 && tt < T && ih >= 0 && ih < H) {
+            const float* rp = video + (((long)b * T + tt) * 3 + ci) * (long)H * W + (long)ih * W;
+            if (iw >= 0 && iw < W) x0 = rp[iw];
+            if (iw + 1 >= 0 && iw + 1 < W) x1 = rp[iw + 1];
+        }
+        *(bf16x2*)&win[((pl * WR + rr) * PW) + 2 * cp] = (bf16x2){(bf16_t)x0, (bf16_t)x1};
+    }
+    // ---- weights: 24 fragments in registers ----
+    bf16x8 wf[SM_KS][4];
+#pragma unroll
+    for (int ks = 0; ks < SM_KS; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) wf[ks][ct] = *(const bf16x8*)(frags + ((ks * 4 + ct) * 64 + lane) * 8);
+    // window offsets of this lane's two rows per K-step (rowid = 8 ks + 2 g + h, clamped onto a real row)
+    const int g = lane >> 4;
+    int roff[SM_KS][2];
+#pragma unroll
+    for (int ks = 0; ks < SM_KS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rowid = min(8 * ks + 2 * g + h, SM_ROWIDS - 1);
+            roff[ks][h] = ((rowid / 3) * WR + rowid % 3) * PW;
+        }
+    __syncthreads();
+
+    const int q = lane >> 4;
+    float sc[4][4], sh[4][4];
+    const bool fold = scale != nullptr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[ct][r] = fold ? scale[16 * ct + 4 * q + r] : 1.f;
+            sh[ct][r] = fold ? shift[16 * ct + 4 * q + r] : 0.f;
+        }
+    f32x4 s1[4], s2[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { s1[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; s2[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int npix = nrow * OW, ntile = (npix + 15) >> 4;
+    for (int tile = wave; tile < ntile; tile += 4) {
+        const int pix = tile * 16 + (lane & 15);
+        const bool live = pix < npix;
+        const int pr = live ? pix / OW : 0, pc = live ? pix - pr * OW : 0;
+        const int base = 2 * pr * PW + 2 * pc;
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < SM_KS; ++ks) {
+            u32x4 a;
+            const unsigned int* r0 = (const unsigned int*)(win + base + roff[ks][0]);
+            const unsigned int* r1 = (const unsigned int*)(win + base + roff[ks][1]);
+            a[0] = r0[0]; a[1] = r0[1]; a[2] = r1[0]; a[3] = r1[1];
+            const bf16x8 xf = __builtin_bit_cast(bf16x8, a);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ct], xf, acc[ct], 0, 0, 0);
+        }
+        if (!live) continue;
+        bf16_t* op = out + (((long)frame * OH + oh0 + pr) * OW + pc) * ST_CO + 4 * q;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[ct][r];
+                s1[ct][r] += v; s2[ct][r] = fmaf(v, v, s2[ct][r]);
+                o[r] = (bf16_t)(fold ? fmaxf(fmaf(v, sc[ct][r], sh[ct][r]), 0.f) : v);
+            }
+            *(bf16x4*)(op + 16 * ct) = o;
+        }
+    }
+    if (csum) {
+        // fold the 16 pixel lanes of each channel quad, then the 4 waves through LDS
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = s1[ct][r], c = s2[ct][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+                if ((lane & 15) == 0) { red[(wave * 2) * 64 + 16 * ct + 4 * q + r] = a; red[(wave * 2 + 1) * 64 + 16 * ct + 4 * q + r] = c; }
+            }
+        __syncthreads();
+        const long part0 = (long)frame * parts_per_frame;
+        if (tid < 64) {
+            float a = 0.f, c = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += red[(w * 2) * 64 + tid]; c += red[(w * 2 + 1) * 64 + tid]; }
+            csum[(part0 + blockIdx.x) * ST_CO + tid] = a;
+            csq[(part0 + blockIdx.x) * ST_CO + tid] = c;
+        }
+        if (blockIdx.x == 0)                          // slab rows of this frame no workgroup owns
+            for (int i = tid; i < (parts_per_frame - (int)gridDim.x) * ST_CO; i += 256) {
+                csum[(part0 + gridDim.x) * ST_CO + i] = 0.f;
+                csq[(part0 + gridDim.x) * ST_CO + i] = 0.f;
+            }
     }
 }
 
@@ -159,29 +314,71 @@ __global__ __launch_bounds__(256) void avgpool_mask_kernel(const T* __restrict__
     }
 }
 
-// number of rows of the [parts, 64] statistics slabs avsr_stem3d_fwd fills
-extern "C" int64_t avsr_stem3d_stats_parts(int64_t B, int64_t T, int64_t H, int64_t W) {
+// Output rows per workgroup of the MFMA stem: the largest of 8, 4, 2, 1 whose bf16 window fits in LDS.
+static int stem_mfma_rows(int64_t W, size_t* lds_bytes) {
+    for (int rows = 8; rows >= 1; rows >>= 1) {
+        const size_t bytes = (size_t)15 * (2 * rows + 1) * (W + 8) * sizeof(bf16_t) + 4 * 2 * 64 * sizeof(float);
+        if (bytes <= 96 * 1024) { *lds_bytes = bytes; return rows; }
+    }
+    return 0;
+}
+static int64_t stem_parts_per_frame(int64_t H, int64_t W) {
     const int64_t OH = (H + 6 - 3) / 2 + 1, OW = (W + 6 - 3) / 2 + 1;
-    return B * T * ((OH * OW + 64 * ST_ROUNDS - 1) / (64 * ST_ROUNDS));
+    const int64_t valu = (OH * OW + 64 * ST_ROUNDS - 1) / (64 * ST_ROUNDS);
+    size_t lds;
+    const int rows = stem_mfma_rows(W, &lds);
+    const int64_t mfma = rows ? (OH + rows - 1) / rows : 0;
+    return valu > mfma ? valu : mfma;
+}
+
+// number of rows of the [parts, 64] statistics slabs avsr_stem3d_fwd fills (either kernel)
+extern "C" int64_t avsr_stem3d_stats_parts(int64_t B, int64_t T, int64_t H, int64_t W) {
+    return B * T * stem_parts_per_frame(H, W);
+}
+
+extern "C" int64_t avsr_stem3d_frag_elems(void) { return SM_FRAG_ELEMS; }
+
+extern "C" int avsr_stem3d_pack_frags(avsr_stream_t stream, const float* weight_packed, void* weight_frags) {
+    if (!weight_packed || !weight_frags) return AVSR_EINVAL;
+    if ((uintptr_t)weight_frags % 16) return AVSR_EUNSUPPORTED;
+    hipLaunchKernelGGL(stem3d_pack_frags_kernel, dim3((SM_FRAG_ELEMS + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       weight_packed, (bf16_t*)weight_frags);
+    return avsr_launch_status();
 }
 
 extern "C" int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float* video, const float* weight_packed,
-                               void* out, const float* scale, const float* shift, float* col_sum, float* col_sumsq,
-                               int64_t B, int64_t T, int64_t H, int64_t W) {
+                               const void* weight_frags, void* out, const float* scale, const float* shift,
+                               float* col_sum, float* col_sumsq, int64_t B, int64_t T, int64_t H, int64_t W) {
     if (!video || !weight_packed || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0) return AVSR_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return AVSR_EINVAL;
     if ((col_sum == nullptr) != (col_sumsq == nullptr)) return AVSR_EINVAL;
     if ((uintptr_t)weight_packed % 16) return AVSR_EUNSUPPORTED;
     const int OH = (int)((H + 6 - 3) / 2 + 1), OW = (int)((W + 6 - 3) / 2 + 1);
-    if (B * T > 65535) return AVSR_EUNSUPPORTED;
-    dim3 grid((unsigned)((OH * OW + 64 * ST_ROUNDS - 1) / (64 * ST_ROUNDS)), (unsigned)(B * T));
+    if (B * T > 65535 || H > 8192 || W > 8192) return AVSR_EUNSUPPORTED;
+    const int ppf = (int)stem_parts_per_frame(H, W);
     hipStream_t s = (hipStream_t)stream;
+    size_t lds = 0;
+    const int rows = stem_mfma_rows(W, &lds);
+    if (out_dtype == AVSR_BF16 && weight_frags && rows > 0 && (W % 2) == 0) {
+        if ((uintptr_t)weight_frags % 16 || (uintptr_t)out % 8) return AVSR_EUNSUPPORTED;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)stem3d_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
+                != hipSuccess) return AVSR_EHIP;
+            attr_set = true;
+        }
+        dim3 grid((unsigned)((OH + rows - 1) / rows), (unsigned)(B * T));
+        hipLaunchKernelGGL(stem3d_mfma_kernel, grid, dim3(256), lds, s, video, (const bf16_t*)weight_frags, (bf16_t*)out,
+                           scale, shift, col_sum, col_sumsq, (int)T, (int)H, (int)W, OH, OW, rows, ppf);
+        return avsr_launch_status();
+    }
+    dim3 grid((unsigned)((OH * OW + 64 * ST_ROUNDS - 1) / (64 * ST_ROUNDS)), (unsigned)(B * T));
     if (out_dtype == AVSR_F32)
         hipLaunchKernelGGL(stem3d_kernel<float>, grid, dim3(256), 0, s, video, weight_packed, (float*)out, scale, shift,
-                           col_sum, col_sumsq, (int)T, (int)H, (int)W, OH, OW);
+                           col_sum, col_sumsq, (int)T, (int)H, (int)W, OH, OW, ppf);
     else if (out_dtype == AVSR_BF16)
         hipLaunchKernelGGL(stem3d_kernel<bf16_t>, grid, dim3(256), 0, s, video, weight_packed, (bf16_t*)out, scale, shift,
-                           col_sum, col_sumsq, (int)T, (int)H, (int)W, OH, OW);
+                           col_sum, col_sumsq, (int)T, (int)H, (int)W, OH, OW, ppf);
     else return AVSR_EINVAL;
     return avsr_launch_status();
 }

@@ -87,6 +87,8 @@ class MoCoVisualFrontend(nn.Module):
             return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
 
         pk = {"stem_w": ops.stem_pack_weight(self.frontend3D[0].weight), "blocks": [], "fold": {}}
+        # bf16: the stem runs as an implicit GEMM on MFMA and needs the weight in fragment order
+        pk["stem_f"] = ops.stem_pack_frags(pk["stem_w"]) if dtype == torch.bfloat16 else None
         if not self.training:      # eval: fold every BN's running statistics once per weight version
             for m in self.modules():
                 if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
@@ -129,9 +131,9 @@ class MoCoVisualFrontend(nn.Module):
         bn0 = self.frontend3D[1]
         if not self.training:
             sc, sh = self._fold(bn0)
-            return ops.maxpool3x3s2(ops.stem3d_fwd(video, pk["stem_w"], dtype, scale=sc, shift=sh))
+            return ops.maxpool3x3s2(ops.stem3d_fwd(video, pk["stem_w"], dtype, scale=sc, shift=sh, frags=pk["stem_f"]))
         stats = ops.stem_stats_slabs(video)
-        raw = ops.stem3d_fwd(video, pk["stem_w"], dtype, col_stats=(stats[0], stats[1]))
+        raw = ops.stem3d_fwd(video, pk["stem_w"], dtype, col_stats=(stats[0], stats[1]), frags=pk["stem_f"])
         aff = torch.empty((2, 64), dtype=torch.float32, device=video.device)
         ops.bn_finalize(stats[0], stats[1], raw.numel() // 64, bn0.weight.detach(), bn0.bias.detach(),
                         bn0.running_mean, bn0.running_var, aff[0], aff[1], bn0.eps, bn0.momentum)

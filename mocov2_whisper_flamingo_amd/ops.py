@@ -220,14 +220,24 @@ def stem_pack_weight(weight):
     return weight.detach().float().reshape(64, 135).t().contiguous()
 
 
+def stem_pack_frags(weight_packed):
+    """bf16 MFMA-fragment copy of a stem_pack_weight() result (the operand of the MFMA stem kernel)."""
+    lib = _lib.load()
+    _need_cuda(weight_packed)
+    frags = torch.empty(int(lib.avsr_stem3d_frag_elems()), dtype=torch.bfloat16, device=weight_packed.device)
+    check(lib.avsr_stem3d_pack_frags(_stream(), weight_packed.data_ptr(), frags.data_ptr()), "avsr_stem3d_pack_frags")
+    return frags
+
+
 def stem_stats_slabs(video):
     B, T, _, H, W = video.shape
     parts = _lib.load().avsr_stem3d_stats_parts(B, T, H, W)
     return torch.empty((2, parts, 64), dtype=torch.float32, device=video.device)
 
 
-def stem3d_fwd(video, weight, out_dtype, *, scale=None, shift=None, col_stats=None):
-    """video [B,T,3,H,W] fp32 contiguous -> NHWC [B*T,OH,OW,64]; weight = stem_pack_weight(w)."""
+def stem3d_fwd(video, weight, out_dtype, *, scale=None, shift=None, col_stats=None, frags=None):
+    """video [B,T,3,H,W] fp32 contiguous -> NHWC [B*T,OH,OW,64]; weight = stem_pack_weight(w);
+    frags = stem_pack_frags(weight) selects the MFMA kernel for bf16 outputs."""
     lib = _lib.load()
     _need_cuda(video, weight)
     if video.dtype != torch.float32 or not video.is_contiguous() or weight.dtype != torch.float32:
@@ -238,7 +248,7 @@ def stem3d_fwd(video, weight, out_dtype, *, scale=None, shift=None, col_stats=No
     OH, OW = (H + 6 - 3) // 2 + 1, (W + 6 - 3) // 2 + 1
     out = torch.empty((B * T, OH, OW, 64), dtype=out_dtype, device=video.device)
     cs = col_stats or (None, None)
-    check(lib.avsr_stem3d_fwd(_stream(), _DT[out_dtype], video.data_ptr(), weight.contiguous().data_ptr(), out.data_ptr(),
+    check(lib.avsr_stem3d_fwd(_stream(), _DT[out_dtype], video.data_ptr(), weight.contiguous().data_ptr(), _p(frags), out.data_ptr(),
                               _p(scale), _p(shift), _p(cs[0]), _p(cs[1]), B, T, H, W), "avsr_stem3d_fwd")
     return out
 

@@ -245,6 +245,37 @@ def test_attn_mfma_fwd_bwd(dev, p, B, H, Tq, Tk, masked):
     assert torch.equal(fin, torch.isfinite(lse)) and (lse[fin] - lse2[fin]).abs().max() < 2e-2
 
 
+@pytest.mark.parametrize("H,W", [(32, 36), (96, 96), (18, 50)])
+@pytest.mark.parametrize("train", [False, True])
+def test_stem_mfma(dev, H, W, train):
+    """bf16 MFMA stem against conv3d on the bf16-rounded operands (inputs and weights are rounded by the kernel)."""
+    g = torch.Generator().manual_seed(H + W)
+    B, T = 2, 6
+    video = torch.randn(B, T, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 5, 3, 3, generator=g) * 0.1
+    vr, wr = video.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+    conv = F.conv3d(vr.permute(0, 2, 1, 3, 4), wr, stride=(1, 2, 2), padding=(2, 3, 3))      # [B,64,T,OH,OW]
+    wp = ops.stem_pack_weight(w.to(dev))
+    fr = ops.stem_pack_frags(wp)
+    if not train:
+        sc, sh = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.1).to(dev)
+        y = ops.stem3d_fwd(video.to(dev), wp, torch.bfloat16, scale=sc, shift=sh, frags=fr)
+        ref = F.relu(conv * sc.cpu().view(1, 64, 1, 1, 1) + sh.cpu().view(1, 64, 1, 1, 1))
+    else:
+        cs = ops.stem_stats_slabs(video.to(dev))
+        cs.fill_(float("nan"))                              # every slab row must be written
+        y = ops.stem3d_fwd(video.to(dev), wp, torch.bfloat16, col_stats=(cs[0], cs[1]), frags=fr)
+        ref = conv
+        tot, tot2 = cs[0].sum(0).cpu(), cs[1].sum(0).cpu()
+        assert rel_err(tot, conv.sum((0, 2, 3, 4))) < 1e-3 and rel_err(tot2, (conv * conv).sum((0, 2, 3, 4))) < 1e-3
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(B * T, conv.shape[3], conv.shape[4], 64)
+    assert y.shape == ref.shape and rel_err(y, ref) < 1e-2
+    # and against the direct fp32-input kernel (only the input rounding differs)
+    y2 = ops.stem3d_fwd(video.to(dev), wp, torch.bfloat16, **({} if train else dict(scale=sc, shift=sh)),
+                        **(dict(col_stats=(ops.stem_stats_slabs(video.to(dev))[0], ops.stem_stats_slabs(video.to(dev))[1])) if train else {}))
+    assert rel_err(y, y2) < 2e-2
+
+
 @pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
 def test_stem_pool_bn(dev, odt):
     g = torch.Generator().manual_seed(5)
