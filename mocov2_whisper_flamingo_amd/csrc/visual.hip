@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void stem3d_kernel(const float* __restrict__ v
                                                      TO* __restrict__ out, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, float* __restrict__ csum,
                                                      float* __restrict__ csq, int T, int H, int W, int OH, int OW,
-                                                     int parts_per_frame) {
+                                                     int parts_per_clip) {
     __shared__ __attribute__((aligned(16))) float ws[ST_TAPS * ST_CO];
     for (int i = threadIdx.x; i < ST_TAPS * ST_CO / 4; i += 256) ((f32x4*)ws)[i] = ((const f32x4*)wpacked)[i];
     __syncthreads();
@@ -93,16 +93,17 @@ __global__ __launch_bounds__(256) void stem3d_kernel(const float* __restrict__ v
         }
     }
     if (csum) {
-        const long part = (long)frame * parts_per_frame + blockIdx.x;
+        const long part0 = (long)b * parts_per_clip;
+        const long part = part0 + (long)t * gridDim.x + blockIdx.x;
 #pragma unroll
         for (int c = 0; c < ST_CPW; ++c) {
             const float s = wave_sum(st1[c]), s2 = wave_sum(st2[c]);
             if (lane == 0) { csum[part * ST_CO + c0 + c] = s; csq[part * ST_CO + c0 + c] = s2; }
         }
-        if (blockIdx.x == 0)                          // slab rows of this frame no workgroup owns
-            for (int i = threadIdx.x; i < (parts_per_frame - (int)gridDim.x) * ST_CO; i += 256) {
-                csum[((long)frame * parts_per_frame + gridDim.x) * ST_CO + i] = 0.f;
-                csq[((long)frame * parts_per_frame + gridDim.x) * ST_CO + i] = 0.f;
+        if (t == 0 && blockIdx.x == 0)                // slab rows of this clip no workgroup owns
+            for (int i = threadIdx.x; i < (parts_per_clip - T * (int)gridDim.x) * ST_CO; i += 256) {
+                csum[(part0 + (long)T * gridDim.x) * ST_CO + i] = 0.f;
+                csq[(part0 + (long)T * gridDim.x) * ST_CO + i] = 0.f;
             }
     }
 }
@@ -134,55 +135,45 @@ __global__ void stem3d_pack_frags_kernel(const float* __restrict__ wpacked, bf16
     frags[i] = (bf16_t)v;
 }
 
+// One work item = SM_F consecutive output frames x `rows` output rows of one clip; its window holds the
+// SM_F + 4 input frames those outputs touch, so an input frame is staged (SM_F + 4) / SM_F = 2 times instead
+// of 5.  Workgroups are persistent (grid = a few per CU) and walk the items, so the 24 weight fragments are
+// loaded once per wave and neighbouring workgroups drift out of phase (staging of one overlaps the MFMA
+// phase of the other).  Statistics of item i go to slab row clip*parts_per_clip + i; the rows of a clip no
+// item owns are zeroed by the clip's first item.
+#define SM_F 4
 __global__ __launch_bounds__(256) void stem3d_mfma_kernel(const float* __restrict__ video, const bf16_t* __restrict__ frags,
                                                          bf16_t* __restrict__ out, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float* __restrict__ csum,
-                                                         float* __restrict__ csq, int T, int H, int W, int OH, int OW,
-                                                         int rows, int parts_per_frame) {
+                                                         float* __restrict__ csq, int B, int T, int H, int W, int OH, int OW,
+                                                         int rows, int parts_per_clip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* win = (bf16_t*)smem;                     // [15 planes][2*rows+1][PW]
-    const int PW = W + 8, WR = 2 * rows + 1;
-    float* red = (float*)(smem + (size_t)15 * WR * PW * sizeof(bf16_t));   // [4 waves][2][64]
-    const int frame = blockIdx.y, b = frame / T, t = frame - b * T;
-    const int oh0 = blockIdx.x * rows;
-    const int nrow = min(rows, OH - oh0);
+    bf16_t* win = (bf16_t*)smem;                     // [(SM_F+4)*3 planes][2*rows+1][PW]
+    const int PW = W + 8, WR = 2 * rows + 1, NPL = (SM_F + 4) * 3;
+    const int plane_sz = WR * PW;
+    float* red = (float*)(smem + (size_t)NPL * plane_sz * sizeof(bf16_t));   // [4 waves][2][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4;
+    const int RB = (OH + rows - 1) / rows, NFG = (T + SM_F - 1) / SM_F;
+    const int items_per_clip = NFG * RB, nitems = B * items_per_clip;
 
-    // ---- stage the window: pairs of columns, zero outside the image / the clip ----
-    const int PP = PW >> 1;
-    for (int i = tid; i < 15 * WR * PP; i += 256) {
-        const int cp = i % PP, rr = (i / PP) % WR, pl = i / (PP * WR);
-        const int ci = pl % 3, tt = t + pl / 3 - 2;
-        const int ih = 2 * oh0 - 3 + rr, iw = 2 * cp - 3;
-        float x0 = 0.f, x1 = 0.f;
-        if (tt >= 0 && tt < T && ih >= 0 && ih < H) {
-            const float* rp = video + (((long)b * T + tt) * 3 + ci) * (long)H * W + (long)ih * W;
-            if (iw >= 0 && iw < W) x0 = rp[iw];
-            if (iw + 1 >= 0 && iw + 1 < W) x1 = rp[iw + 1];
-        }
-        *(bf16x2*)&win[((pl * WR + rr) * PW) + 2 * cp] = (bf16x2){(bf16_t)x0, (bf16_t)x1};
-    }
-    // ---- weights: 24 fragments in registers ----
+    // ---- weights: 24 fragments in registers, once per wave ----
     bf16x8 wf[SM_KS][4];
 #pragma unroll
     for (int ks = 0; ks < SM_KS; ++ks)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) wf[ks][ct] = *(const bf16x8*)(frags + ((ks * 4 + ct) * 64 + lane) * 8);
-    // window offsets of this lane's two rows per K-step (rowid = 8 ks + 2 g + h, clamped onto a real row)
-    const int g = lane >> 4;
+    // window offsets of this lane's two rows per K-step (rowid = 8 ks + 2 q + h, clamped onto a real row)
     int roff[SM_KS][2];
 #pragma unroll
     for (int ks = 0; ks < SM_KS; ++ks)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int rowid = min(8 * ks + 2 * g + h, SM_ROWIDS - 1);
-            roff[ks][h] = ((rowid / 3) * WR + rowid % 3) * PW;
+            const int rowid = min(8 * ks + 2 * q + h, SM_ROWIDS - 1);
+            roff[ks][h] = (rowid / 3) * plane_sz + (rowid % 3) * PW;
         }
-    __syncthreads();
-
-    const int q = lane >> 4;
-    float sc[4][4], sh[4][4];
     const bool fold = scale != nullptr;
+    float sc[4][4], sh[4][4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -190,69 +181,128 @@ __global__ __launch_bounds__(256) void stem3d_mfma_kernel(const float* __restric
             sc[ct][r] = fold ? scale[16 * ct + 4 * q + r] : 1.f;
             sh[ct][r] = fold ? shift[16 * ct + 4 * q + r] : 0.f;
         }
-    f32x4 s1[4], s2[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) { s1[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; s2[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int W4 = W >> 2, NI = NPL * WR * W4;
+    const int dr = 256 / W4, dj = 256 - dr * W4;
 
-    const int npix = nrow * OW, ntile = (npix + 15) >> 4;
-    for (int tile = wave; tile < ntile; tile += 4) {
-        const int pix = tile * 16 + (lane & 15);
-        const bool live = pix < npix;
-        const int pr = live ? pix / OW : 0, pc = live ? pix - pr * OW : 0;
-        const int base = 2 * pr * PW + 2 * pc;
-        f32x4 acc[4];
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int b = item / items_per_clip, ic = item - b * items_per_clip;
+        const int fg = ic / RB, rbk = ic - fg * RB;
+        const int t0 = fg * SM_F, nf = min(SM_F, T - t0);
+        const int oh0 = rbk * rows, nrow = min(rows, OH - oh0);
+        __syncthreads();                                  // the previous item's window is fully read
+
+        // ---- stage the window: 16-byte loads, 8 in flight per thread, zero outside the image / the clip.
+        // Loads are unconditional from clamped addresses and zeroed afterwards (a load under a branch gets
+        // its own s_waitcnt vmcnt(0), which serialises the memory latency).  Window column = image column + 3.
+        // Entry i = (window row r, 4-column group j) advances by 256 per load, tracked without divisions.
+        {
+            int r = tid / W4, j = tid - r * W4;
+            int pl = r / WR, rr = r - pl * WR;
+            for (int i0 = tid; i0 < NI; i0 += 256 * 8) {
+                f32x4 v[8];
+                int wofs[8];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = i0 + 256 * u < NI;
+                    const int plc = min(pl, NPL - 1);
+                    const int ci = plc % 3, tt = t0 + plc / 3 - 2;
+                    const int ih = 2 * oh0 - 3 + rr;
+                    const bool rok = in && tt >= 0 && tt < T && ih >= 0 && ih < H;
+                    const int ttc = min(max(tt, 0), T - 1), ihc = min(max(ih, 0), H - 1);
+                    v[u] = *(const f32x4*)(video + ((((long)b * T + ttc) * 3 + ci) * H + ihc) * (long)W + 4 * j);
+                    if (!rok) v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    wofs[u] = in ? pl * plane_sz + rr * PW + 4 * j : -1;
+                    j += dj; rr += dr;
+                    if (j >= W4) { j -= W4; ++rr; }
+                    while (rr >= WR) { rr -= WR; ++pl; }
+                }
 #pragma unroll
-        for (int ks = 0; ks < SM_KS; ++ks) {
-            u32x4 a;
-            const unsigned int* r0 = (const unsigned int*)(win + base + roff[ks][0]);
-            const unsigned int* r1 = (const unsigned int*)(win + base + roff[ks][1]);
-            a[0] = r0[0]; a[1] = r0[1]; a[2] = r1[0]; a[3] = r1[1];
-            const bf16x8 xf = __builtin_bit_cast(bf16x8, a);
+                for (int u = 0; u < 8; ++u) {
+                    if (wofs[u] >= 0) {
+                        bf16_t* wp = win + wofs[u];
+                        wp[3] = (bf16_t)v[u][0];
+                        *(bf16x2*)(wp + 4) = (bf16x2){(bf16_t)v[u][1], (bf16_t)v[u][2]};
+                        wp[6] = (bf16_t)v[u][3];
+                    }
+                }
+            }
+            for (int r2 = tid; r2 < NPL * WR; r2 += 256) {    // the 3 + 5 padding columns of every window row
+                bf16_t* wp = win + r2 * PW;
+                wp[0] = wp[1] = wp[2] = (bf16_t)0.f;
+#pragma unroll
+                for (int c = 3; c < 8; ++c) wp[W + c] = (bf16_t)0.f;
+            }
+        }
+        __syncthreads();
+
+        f32x4 s1[4], s2[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { s1[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; s2[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        const int fpix = nrow * OW, npix = nf * fpix;
+        const int ntile = (npix + 15) >> 4;
+        for (int tile = wave; tile < ntile; tile += 4) {
+            const int pix = tile * 16 + (lane & 15);
+            const bool live = pix < npix;
+            const int pf = live ? pix / fpix : 0, prem = live ? pix - pf * fpix : 0;
+            const int pr = prem / OW, pc = prem - pr * OW;
+            const int base = pf * 3 * plane_sz + 2 * pr * PW + 2 * pc;
+            f32x4 acc[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < SM_KS; ++ks) {
+                u32x4 a;
+                const unsigned int* r0 = (const unsigned int*)(win + base + roff[ks][0]);
+                const unsigned int* r1 = (const unsigned int*)(win + base + roff[ks][1]);
+                a[0] = r0[0]; a[1] = r0[1]; a[2] = r1[0]; a[3] = r1[1];
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, a);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ct], xf, acc[ct], 0, 0, 0);
+            }
+            if (!live) continue;
+            bf16_t* op = out + ((((long)b * T + t0 + pf) * OH + oh0 + pr) * OW + pc) * ST_CO + 4 * q;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[ct][r];
+                    s1[ct][r] += v; s2[ct][r] = fmaf(v, v, s2[ct][r]);
+                    o[r] = (bf16_t)(fold ? fmaxf(fmaf(v, sc[ct][r], sh[ct][r]), 0.f) : v);
+                }
+                *(bf16x4*)(op + 16 * ct) = o;
+            }
+        }
+        if (csum) {
+            // fold the 16 pixel lanes of each channel quad, then the 4 waves through LDS
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ct], xf, acc[ct], 0, 0, 0);
-        }
-        if (!live) continue;
-        bf16_t* op = out + (((long)frame * OH + oh0 + pr) * OW + pc) * ST_CO + 4 * q;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            bf16x4 o;
+                for (int r = 0; r < 4; ++r) {
+                    float a = s1[ct][r], c = s2[ct][r];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = acc[ct][r];
-                s1[ct][r] += v; s2[ct][r] = fmaf(v, v, s2[ct][r]);
-                o[r] = (bf16_t)(fold ? fmaxf(fmaf(v, sc[ct][r], sh[ct][r]), 0.f) : v);
+                    for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+                    if ((lane & 15) == 0) {
+                        red[(wave * 2) * 64 + 16 * ct + 4 * q + r] = a;
+                        red[(wave * 2 + 1) * 64 + 16 * ct + 4 * q + r] = c;
+                    }
+                }
+            __syncthreads();
+            const long part0 = (long)b * parts_per_clip;
+            if (tid < 64) {
+                float a = 0.f, c = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { a += red[(w * 2) * 64 + tid]; c += red[(w * 2 + 1) * 64 + tid]; }
+                csum[(part0 + ic) * ST_CO + tid] = a;
+                csq[(part0 + ic) * ST_CO + tid] = c;
             }
-            *(bf16x4*)(op + 16 * ct) = o;
+            if (ic == 0)                                  // slab rows of this clip no item owns
+                for (int i = tid; i < (parts_per_clip - items_per_clip) * ST_CO; i += 256) {
+                    csum[(part0 + items_per_clip) * ST_CO + i] = 0.f;
+                    csq[(part0 + items_per_clip) * ST_CO + i] = 0.f;
+                }
         }
-    }
-    if (csum) {
-        // fold the 16 pixel lanes of each channel quad, then the 4 waves through LDS
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = s1[ct][r], c = s2[ct][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
-                if ((lane & 15) == 0) { red[(wave * 2) * 64 + 16 * ct + 4 * q + r] = a; red[(wave * 2 + 1) * 64 + 16 * ct + 4 * q + r] = c; }
-            }
-        __syncthreads();
-        const long part0 = (long)frame * parts_per_frame;
-        if (tid < 64) {
-            float a = 0.f, c = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { a += red[(w * 2) * 64 + tid]; c += red[(w * 2 + 1) * 64 + tid]; }
-            csum[(part0 + blockIdx.x) * ST_CO + tid] = a;
-            csq[(part0 + blockIdx.x) * ST_CO + tid] = c;
-        }
-        if (blockIdx.x == 0)                          // slab rows of this frame no workgroup owns
-            for (int i = tid; i < (parts_per_frame - (int)gridDim.x) * ST_CO; i += 256) {
-                csum[(part0 + gridDim.x) * ST_CO + i] = 0.f;
-                csq[(part0 + gridDim.x) * ST_CO + i] = 0.f;
-            }
     }
 }
 
@@ -314,26 +364,26 @@ __global__ __launch_bounds__(256) void avgpool_mask_kernel(const T* __restrict__
     }
 }
 
-// Output rows per workgroup of the MFMA stem: the largest of 8, 4, 2, 1 whose bf16 window fits in LDS.
+// Output rows per work item of the MFMA stem: the largest of 4, 2, 1 whose bf16 window fits in LDS twice per CU.
 static int stem_mfma_rows(int64_t W, size_t* lds_bytes) {
-    for (int rows = 8; rows >= 1; rows >>= 1) {
-        const size_t bytes = (size_t)15 * (2 * rows + 1) * (W + 8) * sizeof(bf16_t) + 4 * 2 * 64 * sizeof(float);
-        if (bytes <= 96 * 1024) { *lds_bytes = bytes; return rows; }
+    for (int rows = 4; rows >= 1; rows >>= 1) {
+        const size_t bytes = (size_t)(SM_F + 4) * 3 * (2 * rows + 1) * (W + 8) * sizeof(bf16_t) + 4 * 2 * 64 * sizeof(float);
+        if (bytes <= 72 * 1024) { *lds_bytes = bytes; return rows; }
     }
     return 0;
 }
-static int64_t stem_parts_per_frame(int64_t H, int64_t W) {
+static int64_t stem_parts_per_clip(int64_t T, int64_t H, int64_t W) {
     const int64_t OH = (H + 6 - 3) / 2 + 1, OW = (W + 6 - 3) / 2 + 1;
-    const int64_t valu = (OH * OW + 64 * ST_ROUNDS - 1) / (64 * ST_ROUNDS);
+    const int64_t valu = T * ((OH * OW + 64 * ST_ROUNDS - 1) / (64 * ST_ROUNDS));
     size_t lds;
     const int rows = stem_mfma_rows(W, &lds);
-    const int64_t mfma = rows ? (OH + rows - 1) / rows : 0;
+    const int64_t mfma = rows ? ((T + SM_F - 1) / SM_F) * ((OH + rows - 1) / rows) : 0;
     return valu > mfma ? valu : mfma;
 }
 
 // number of rows of the [parts, 64] statistics slabs avsr_stem3d_fwd fills (either kernel)
 extern "C" int64_t avsr_stem3d_stats_parts(int64_t B, int64_t T, int64_t H, int64_t W) {
-    return B * T * stem_parts_per_frame(H, W);
+    return B * stem_parts_per_clip(T, H, W);
 }
 
 extern "C" int64_t avsr_stem3d_frag_elems(void) { return SM_FRAG_ELEMS; }
@@ -355,11 +405,11 @@ extern "C" int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float*
     if ((uintptr_t)weight_packed % 16) return AVSR_EUNSUPPORTED;
     const int OH = (int)((H + 6 - 3) / 2 + 1), OW = (int)((W + 6 - 3) / 2 + 1);
     if (B * T > 65535 || H > 8192 || W > 8192) return AVSR_EUNSUPPORTED;
-    const int ppf = (int)stem_parts_per_frame(H, W);
+    const int ppc = (int)stem_parts_per_clip(T, H, W);
     hipStream_t s = (hipStream_t)stream;
     size_t lds = 0;
     const int rows = stem_mfma_rows(W, &lds);
-    if (out_dtype == AVSR_BF16 && weight_frags && rows > 0 && (W % 2) == 0) {
+    if (out_dtype == AVSR_BF16 && weight_frags && rows > 0 && (W % 4) == 0 && (uintptr_t)video % 16 == 0) {
         if ((uintptr_t)weight_frags % 16 || (uintptr_t)out % 8) return AVSR_EUNSUPPORTED;
         static bool attr_set = false;
         if (!attr_set) {
@@ -367,18 +417,19 @@ extern "C" int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float*
                 != hipSuccess) return AVSR_EHIP;
             attr_set = true;
         }
-        dim3 grid((unsigned)((OH + rows - 1) / rows), (unsigned)(B * T));
-        hipLaunchKernelGGL(stem3d_mfma_kernel, grid, dim3(256), lds, s, video, (const bf16_t*)weight_frags, (bf16_t*)out,
-                           scale, shift, col_sum, col_sumsq, (int)T, (int)H, (int)W, OH, OW, rows, ppf);
+        const long nitems = B * ((T + SM_F - 1) / SM_F) * ((OH + rows - 1) / rows);
+        const unsigned nblk = (unsigned)(nitems < 512 ? nitems : 512);      // persistent: two workgroups per CU
+        hipLaunchKernelGGL(stem3d_mfma_kernel, dim3(nblk), dim3(256), lds, s, video, (const bf16_t*)weight_frags,
+                           (bf16_t*)out, scale, shift, col_sum, col_sumsq, (int)B, (int)T, (int)H, (int)W, OH, OW, rows, ppc);
         return avsr_launch_status();
     }
     dim3 grid((unsigned)((OH * OW + 64 * ST_ROUNDS - 1) / (64 * ST_ROUNDS)), (unsigned)(B * T));
     if (out_dtype == AVSR_F32)
         hipLaunchKernelGGL(stem3d_kernel<float>, grid, dim3(256), 0, s, video, weight_packed, (float*)out, scale, shift,
-                           col_sum, col_sumsq, (int)T, (int)H, (int)W, OH, OW, ppf);
+                           col_sum, col_sumsq, (int)T, (int)H, (int)W, OH, OW, ppc);
     else if (out_dtype == AVSR_BF16)
         hipLaunchKernelGGL(stem3d_kernel<bf16_t>, grid, dim3(256), 0, s, video, weight_packed, (bf16_t*)out, scale, shift,
-                           col_sum, col_sumsq, (int)T, (int)H, (int)W, OH, OW, ppf);
+                           col_sum, col_sumsq, (int)T, (int)H, (int)W, OH, OW, ppc);
     else return AVSR_EINVAL;
     return avsr_launch_status();
 }

@@ -245,7 +245,7 @@ def test_attn_mfma_fwd_bwd(dev, p, B, H, Tq, Tk, masked):
     assert torch.equal(fin, torch.isfinite(lse)) and (lse[fin] - lse2[fin]).abs().max() < 2e-2
 
 
-@pytest.mark.parametrize("H,W", [(32, 36), (96, 96), (18, 50)])
+@pytest.mark.parametrize("H,W", [(32, 36), (96, 96), (18, 52), (18, 50)])
 @pytest.mark.parametrize("train", [False, True])
 def test_stem_mfma(dev, H, W, train):
     """bf16 MFMA stem against conv3d on the bf16-rounded operands (inputs and weights are rounded by the kernel)."""
@@ -267,7 +267,8 @@ def test_stem_mfma(dev, H, W, train):
         y = ops.stem3d_fwd(video.to(dev), wp, torch.bfloat16, col_stats=(cs[0], cs[1]), frags=fr)
         ref = conv
         tot, tot2 = cs[0].sum(0).cpu(), cs[1].sum(0).cpu()
-        assert rel_err(tot, conv.sum((0, 2, 3, 4))) < 1e-3 and rel_err(tot2, (conv * conv).sum((0, 2, 3, 4))) < 1e-3
+        stol = 1e-3 if W % 4 == 0 else 1e-2     # W % 4 != 0 falls back to the direct kernel, which does not round the input
+        assert rel_err(tot, conv.sum((0, 2, 3, 4))) < stol and rel_err(tot2, (conv * conv).sum((0, 2, 3, 4))) < stol
     ref = ref.permute(0, 2, 3, 4, 1).reshape(B * T, conv.shape[3], conv.shape[4], 64)
     assert y.shape == ref.shape and rel_err(y, ref) < 1e-2
     # and against the direct fp32-input kernel (only the input rounding differs)
