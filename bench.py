@@ -149,7 +149,7 @@ def main():
         ops.GEMM_PROFILE = []
         step()
         torch.cuda.synchronize()
-        recs = [(a.elapsed_time(b) * 1e-3, fl) for a, b, fl, tag, _shape in ops.GEMM_PROFILE if tag == "bf16"]
+        recs = [(a.elapsed_time(b) * 1e-3, fl) for a, b, fl, tag, *_rest in ops.GEMM_PROFILE if tag == "bf16"]
         ops.GEMM_PROFILE = None
         tsum, fsum = sum(r[0] for r in recs), sum(r[1] for r in recs)
         achieved = fsum / tsum / 1e12

@@ -227,9 +227,10 @@ int avsr_argmax_rows(avsr_stream_t stream, const float* x, int64_t ld, int64_t r
  * Element-wise helpers around the GEMMs.
  * ---------------------------------------------------------------------- */
 int avsr_cast(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y, int64_t n, float scale);
-/* y[b][c][r] = x[b][r][c] * scale */
+/* y[b][c][r] = x[b][r][c] * scale; copy (optional, batch 1): copy[r*ldc + c] = x[r][c] * scale in out_dtype */
 int avsr_transpose(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, int64_t ldx, int64_t sx,
-                   void* y, int64_t ldy, int64_t sy, int64_t batch, int64_t R, int64_t C, float scale);
+                   void* y, int64_t ldy, int64_t sy, int64_t batch, int64_t R, int64_t C, float scale,
+                   void* copy, int64_t ldc);
 /* out[n] (+)= sum_m x[m][n]  (bias gradients) */
 int avsr_colsum(avsr_stream_t stream, int dtype, const void* x, int64_t ld, int64_t M, int64_t N, float* out,
                 int accumulate);

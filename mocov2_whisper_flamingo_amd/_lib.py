@@ -64,7 +64,7 @@ SIGNATURES = {
                                   _vp, _f32, _f32, _vp, _vp, _vp, _i64]),
     "avsr_argmax_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "avsr_cast": (_i32, [_vp, _i32, _i32, _vp, _vp, _i64, _f32]),
-    "avsr_transpose": (_i32, [_vp, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _f32]),
+    "avsr_transpose": (_i32, [_vp, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _vp, _i64]),
     "avsr_colsum": (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _vp, _i32]),
     "avsr_gelu_fwd": (_i32, [_vp, _i32, _vp, _vp, _i64]),
     "avsr_gelu_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64]),

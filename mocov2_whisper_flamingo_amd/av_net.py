@@ -120,7 +120,8 @@ class AVNet(nn.Module):
         out, B, T = self._features(inputBatch)
         lin = self.decoder.linear
         wc, wct = self._cache.get(lin.weight)
-        logits = Fn.LinearFn.apply(out, lin.weight, lin.bias, wc, wct, torch.float32, wct.shape[1])
+        logits = Fn.LinearFn.apply(out, lin.weight, lin.bias, wc, wct, torch.float32, wct.shape[1],
+                                   (lin.weight, lin.bias, None, 1))
         return logits.view(B, T, -1)
 
     def training_step(self, batch, label_smoothing=0.1):

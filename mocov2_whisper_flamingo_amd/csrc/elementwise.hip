@@ -16,10 +16,12 @@ __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO*
     }
 }
 
-// y[b][c][r] = x[b][r][c] * scale  (32x32 LDS tile, padded against bank conflicts)
+// y[b][c][r] = x[b][r][c] * scale  (32x32 LDS tile, padded against bank conflicts); `copy`, when given,
+// also receives the untransposed x * scale in the output type ([R, ldc] rows, batch 1 only): a weight's
+// compute-dtype copy and its transpose in one pass.
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ x, long ldx, long sx, TO* __restrict__ y, long ldy,
-                                                        long sy, int R, int C, float scale) {
+                                                        long sy, int R, int C, float scale, TO* __restrict__ copy, long ldc) {
     __shared__ float tile[32][33];
     const TI* xb = x + (long)blockIdx.z * sx;
     TO* yb = y + (long)blockIdx.z * sy;
@@ -27,7 +29,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ x
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < C) ? to_f32<TI>(xb[(long)r * ldx + c]) * scale : 0.f;
+        const bool in = r < R && c < C;
+        const float v = in ? to_f32<TI>(xb[(long)r * ldx + c]) * scale : 0.f;
+        tile[i][tx] = v;
+        if (copy && in) copy[(long)r * ldc + c] = from_f32<TO>(v);
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
@@ -202,13 +207,15 @@ extern "C" int avsr_cast(avsr_stream_t stream, int in_dtype, int out_dtype, cons
 }
 
 extern "C" int avsr_transpose(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, int64_t ldx, int64_t sx,
-                              void* y, int64_t ldy, int64_t sy, int64_t batch, int64_t R, int64_t C, float scale) {
+                              void* y, int64_t ldy, int64_t sy, int64_t batch, int64_t R, int64_t C, float scale,
+                              void* copy, int64_t ldc) {
     if (!x || !y || batch <= 0 || R <= 0 || C <= 0 || batch > 65535) return AVSR_EINVAL;
+    if (copy && (batch != 1 || ldc < C)) return AVSR_EINVAL;
     if ((R + 31) / 32 > 65535) return AVSR_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32), (unsigned)batch), block(256);
 #define L(TI, TO) hipLaunchKernelGGL((transpose_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, (long)ldx, (long)sx, (TO*)y, \
-                                     (long)ldy, (long)sy, (int)R, (int)C, scale)
+                                     (long)ldy, (long)sy, (int)R, (int)C, scale, (TO*)copy, (long)ldc)
     if (in_dtype == AVSR_F32 && out_dtype == AVSR_BF16) L(float, bf16_t);
     else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_F32) L(bf16_t, float);
     else if (in_dtype == AVSR_F32 && out_dtype == AVSR_F32) L(float, float);

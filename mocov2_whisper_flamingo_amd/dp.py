@@ -86,6 +86,11 @@ class FlatTrainer:
         self.overlap = overlap and self.world > 1
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.on_gpu and self.world > 1) else None
         self._works = []
+        # the backward kernels accumulate straight into the flat gradient buffer (functional.grad_sink);
+        # gradients that still arrive through autograd keep the ordinary post-accumulate hook
+        for _, p in self.named:
+            p._avsr_direct_grad = self.on_gpu
+            p._avsr_grad_hook = self._on_grad_ready if self.overlap else None
         if self.overlap:
             for _, p in self.named:
                 p.register_post_accumulate_grad_hook(self._on_grad_ready)

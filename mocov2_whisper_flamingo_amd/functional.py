@@ -34,14 +34,70 @@ class WeightCache:
             return hit[1], hit[2]
         with torch.no_grad():
             w = p.detach()
-            wc = w if self.dtype == torch.float32 else ops.cast(w, self.dtype)
             # big vocabulary heads: pad N so the dX product can split its K (= N) 16 ways in 64-element steps
-            wct = ops.transpose2d(w, dtype=self.dtype, pad_to=1024 if w.shape[0] > 16384 else 8)
+            pad = 1024 if w.shape[0] > 16384 else 8
+            if self.dtype == torch.float32:
+                wc, wct = w, ops.transpose2d(w, dtype=self.dtype, pad_to=pad)
+            else:                      # compute-dtype copy and its transpose in one pass over the fp32 master
+                wct, wc = ops.transpose2d(w, dtype=self.dtype, pad_to=pad, with_copy=True)
         self._store[key] = (ver, wc, wct)
         return wc, wct
 
     def clear(self):
         self._store.clear()
+
+
+def grad_sink(p, rows=None):
+    """fp32 buffer the backward kernels may ACCUMULATE the gradient of parameter ``p`` (or of its row
+    range ``rows``) into directly, or None (= hand the gradient back to autograd).  A parameter owner
+    opts in with ``p._avsr_direct_grad = True`` and a preallocated fp32 ``p.grad`` (``dp.FlatTrainer``
+    does); this removes one temporary, one fill and one add kernel per parameter and step.  Only valid
+    under ``loss.backward()`` - ``torch.autograd.grad`` callers must leave the flag unset."""
+    if p is None or not getattr(p, "_avsr_direct_grad", False):
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous():
+        return None
+    return g if rows is None else g[rows[0]:rows[1]]
+
+
+def grad_done(p, parts=1):
+    """Tell the parameter's owner that its gradient (``parts`` pieces per step) is complete: stands in
+    for the post-accumulate-grad hook autograd would have run."""
+    hook = getattr(p, "_avsr_grad_hook", None) if p is not None else None
+    if hook is None:
+        return
+    if parts > 1:
+        left = getattr(p, "_avsr_parts_left", parts) - 1
+        p._avsr_parts_left = left if left > 0 else parts
+        if left > 0:
+            return
+    hook(p)
+
+
+def _param_grads(dy, x, has_bias, sink):
+    """dW = dY^T X and db = column sums of dY: returned, or accumulated into the sink buffers."""
+    pw, pb, rows, parts = sink if sink is not None else (None, None, None, 1)
+    dyt = ops.transpose2d(dy, pad_to=8)                     # [N, Mp]
+    xt = ops.transpose2d(x, pad_to=8)                       # [K, Mp]
+    gw = grad_sink(pw, rows)
+    if gw is not None:
+        ops.gemm_nt(dyt, xt, out=gw, residual=gw)
+        dw = None
+    else:
+        dw = ops.gemm_nt(dyt, xt, out_dtype=torch.float32)  # [N, K]
+    db = None
+    if has_bias:
+        gb = grad_sink(pb, rows)
+        if gb is not None:
+            ops.colsum(dy, out=gb, accumulate=True)
+        else:
+            db = ops.colsum(dy)
+    if gw is not None:
+        grad_done(pw, parts)
+    if has_bias and db is None:
+        grad_done(pb, parts)
+    return dw, db
 
 
 def _dx_gemm(dy, wct):
@@ -59,8 +115,11 @@ class LinearFn(Function):
     compute-dtype copies the kernels read."""
 
     @staticmethod
-    def forward(ctx, x, w, b, wc, wct, out_dtype, ld_out):
+    def forward(ctx, x, w, b, wc, wct, out_dtype, ld_out, sink=None):
+        """``sink`` = (weight parameter, bias parameter, row range or None, pieces per step): where the
+        parameter gradients may be accumulated directly (see ``grad_sink``)."""
         N = wc.shape[0]
+        ctx.sink = sink
         if ld_out is None:
             y = ops.gemm_nt(x, wc, bias=b, out_dtype=out_dtype)
         else:   # padded leading dimension: the result is a [M, N] view of a [M, ld_out] buffer
@@ -84,11 +143,8 @@ class LinearFn(Function):
             dy = pad[:, :N]
         dyk = dy if Np == N else torch.as_strided(dy, (M, Np), (dy.stride(0), 1))   # padding columns are zero
         dx = _dx_gemm(dyk, wct) if ctx.needs_input_grad[0] else None
-        dyt = ops.transpose2d(dy, pad_to=8)                     # [N, Mp]
-        xt = ops.transpose2d(x, pad_to=8)                       # [K, Mp]
-        dw = ops.gemm_nt(dyt, xt, out_dtype=torch.float32)      # [N, K]
-        db = ops.colsum(dy) if ctx.has_bias else None
-        return dx, dw, db, None, None, None, None
+        dw, db = _param_grads(dy, x, ctx.has_bias, ctx.sink)
+        return dx, dw, db, None, None, None, None, None
 
 
 class LayerNormFn(Function):
@@ -98,15 +154,23 @@ class LayerNormFn(Function):
     def forward(ctx, x, gamma, beta, add):
         y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, add=add, save_stats=True)
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(gamma)
+        pg, pb = ctx.params
+        sg, sb = grad_sink(pg), grad_sink(pb)
+        direct = sg is not None and sb is not None
+        dg = sg if direct else torch.zeros_like(gamma)          # the kernel accumulates into both
+        db = sb if direct else torch.zeros_like(gamma)
         dy = dy if dy.stride(-1) == 1 else dy.contiguous()
         dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db)
+        if direct:
+            grad_done(pg)
+            grad_done(pb)
+            return dx, None, None, None
         return dx, dg, db, None
 
 
@@ -129,14 +193,19 @@ class GatedResidualFn(Function):
     def forward(ctx, x, y, gate, p_drop, seed):
         ctx.save_for_backward(y, gate)
         ctx.p_drop, ctx.seed = p_drop, seed
+        ctx.gate_param = gate
         return ops.gated_residual_fwd(x, y, gate, p_drop, seed)
 
     @staticmethod
     def backward(ctx, dout):
         y, gate = ctx.saved_tensors
         dout = dout.contiguous()
-        dgate = torch.zeros_like(gate)
+        sink = grad_sink(ctx.gate_param)
+        dgate = sink if sink is not None else torch.zeros_like(gate)     # the kernel accumulates
         dy = ops.gated_residual_bwd(dout, y, gate, dgate, ctx.p_drop, ctx.seed)
+        if sink is not None:
+            grad_done(ctx.gate_param)
+            return dout, dy, None, None, None
         return dout, dy, dgate, None, None
 
 
@@ -181,6 +250,7 @@ class HeadLossFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, wc, wct, targets, input_lengths, target_lengths, B, T, label_smoothing):
         V = wc.shape[0]
+        ctx.sink = (w, b, None, 1)
         ld = wct.shape[1]
         buf = torch.empty((B * T, ld), dtype=torch.float32, device=x.device)
         ops.gemm_nt(x, wc, bias=b, out=buf[:, :V])
@@ -201,13 +271,13 @@ class HeadLossFn(Function):
         dl = ops.head_loss_bwd(logits, targets, input_lengths, target_lengths, ws, x.dtype, label_smoothing=ls,
                                up_ctc=gc, up_ce=ge, ld_out=ld)                       # [B*T, ld], pad columns zero
         dx = _dx_gemm(dl, wct)
-        dlt = ops.transpose2d(dl[:, :V], pad_to=8)
-        xt = ops.transpose2d(x, pad_to=8)
-        dw = ops.gemm_nt(dlt, xt, out_dtype=torch.float32)
-        db = ops.colsum(dl[:, :V])
+        dw, db = _param_grads(dl[:, :V], x, True, ctx.sink)
         return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def linear(x, w, b, cache_entry, out_dtype=None, ld_out=None):
+def linear(x, w, b, cache_entry, out_dtype=None, ld_out=None, sink=None):
+    """``w`` / ``b`` parameters (sink defaults to them) or row slices of parameters (pass ``sink``)."""
     wc, wct = cache_entry
-    return LinearFn.apply(x, w, b, wc, wct, out_dtype, ld_out)
+    if sink is None and isinstance(w, torch.nn.Parameter):
+        sink = (w, b if isinstance(b, torch.nn.Parameter) else None, None, 1)
+    return LinearFn.apply(x, w, b, wc, wct, out_dtype, ld_out, sink)

@@ -58,8 +58,8 @@ class GatedCrossAttentionBlock(nn.Module):
             wc, wct = cache.get(self.attn.in_proj_weight)
             w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
             h = self.attn_ln(x2)
-            q = Fn.linear(h, w[:d], b[:d], (wc[:d], wct[:, :d]))
-            kv = Fn.linear(xa.reshape(B * Tk, d), w[d:], b[d:], (wc[d:], wct[:, d:]))
+            q = Fn.linear(h, w[:d], b[:d], (wc[:d], wct[:, :d]), sink=(w, b, (0, d), 2))
+            kv = Fn.linear(xa.reshape(B * Tk, d), w[d:], b[d:], (wc[d:], wct[:, d:]), sink=(w, b, (d, 3 * d), 2))
             kv = kv.view(B, Tk, 2 * d)
             a = Fn.AttnFn.apply(q.view(B, T, d), kv[:, :, :d], kv[:, :, d:], km, H, 64 ** -0.5, p,
                                 self._seed_fn("attn"))

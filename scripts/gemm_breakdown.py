@@ -28,15 +28,18 @@ def step():
 for _ in range(3):
     step()
 ops.GEMM_PROFILE = []
+ops.GEMM_PROFILE_REPEAT = '--repeat' in sys.argv
 step()
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
-for a, b, fl, tag, shape in ops.GEMM_PROFILE:
+for a, b, fl, tag, shape, *rep in ops.GEMM_PROFILE:
     t = a.elapsed_time(b) * 1e-3
-    e = agg.setdefault((tag,) + shape, [0, 0.0, 0.0])
+    e = agg.setdefault((tag,) + shape, [0, 0.0, 0.0, 0.0])
     e[0] += 1; e[1] += t; e[2] += fl
+    if rep: e[3] += rep[0].elapsed_time(rep[1]) * 1e-3
 tot = sum(e[1] for e in agg.values())
 print(f"total GEMM time {tot*1e3:.3f} ms in {sum(e[0] for e in agg.values())} launches")
 for k, e in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     tag, M, N, K, batch_, conv = k
-    print(f"{e[1]*1e6:8.1f} us {e[1]/tot*100:5.1f}%  x{e[0]:3d}  {e[2]/e[1]/1e12:7.1f} TF  {tag} M={M} N={N} K={K} b={batch_} conv={conv}")
+    rep = f" | repeat {e[3]*1e6:8.1f} us {e[2]/e[3]/1e12:7.1f} TF" if e[3] else ""
+    print(f"{e[1]*1e6:8.1f} us {e[1]/tot*100:5.1f}%  x{e[0]:3d}  {e[2]/e[1]/1e12:7.1f} TF{rep}  {tag} M={M} N={N} K={K} b={batch_} conv={conv}")

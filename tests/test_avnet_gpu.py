@@ -297,3 +297,45 @@ def test_head_losses_vs_golden(dev):
     targets = torch.randint(1, V, (B, L), generator=gen)
     out3, _ = ops.head_loss_fwd(logits, targets.to(dev), torch.full((B,), T, device=dev), torch.full((B,), L, device=dev))
     assert abs(out3[0].item() - float(g["ctc"])) < 1e-4 and abs(out3[1].item() - float(g["ce"])) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_flat_trainer_direct_gradients_match_autograd(dev, dtype):
+    """FlatTrainer lets the backward kernels accumulate parameter gradients straight into its flat buffer
+    (functional.grad_sink); the result must equal what autograd's own accumulation produces, including a
+    second backward into the same buffers (accumulation, not overwrite)."""
+    from mocov2_whisper_flamingo_amd.dp import FlatTrainer, trainable_parameters
+    ma, _ = _micro_avnet(dtype, dev, p_drop=0.2)
+    mb, _ = _micro_avnet(dtype, dev, p_drop=0.2)
+    for m in (ma, mb):
+        m.train()
+        with torch.no_grad():
+            for blk in m.fusion_module.layers:
+                blk.attn_gate.fill_(0.4)
+                blk.ff_gate.fill_(-0.3)
+    tr = FlatTrainer(mb)
+    assert all(getattr(p, "_avsr_direct_grad", False) for _, p in trainable_parameters(mb))
+    batch = to_device(synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=31), dev)
+
+    def run(m):
+        b = dict(batch)
+        b["video_lengths"] = batch["video_lengths"].clone()
+        loss, *_ = m.training_step(b)
+        loss.backward()
+        return loss
+
+    tr.zero_grad()
+    la, lb = run(ma), run(mb)
+    assert torch.allclose(la, lb, rtol=1e-6, atol=1e-6)
+    named_a = dict(trainable_parameters(ma))
+    for rep in range(2):
+        for n, p in trainable_parameters(mb):
+            ga, gb = named_a[n].grad, p.grad
+            assert ga is not None and gb is not None, n
+            assert gb.data_ptr() >= tr.flat_grad.data_ptr()            # still a view of the flat buffer
+            ref = ga.float()
+            tol = (1e-5 if dtype == torch.float32 else 2e-2) * max(1.0, float(ref.abs().max()))
+            assert float((gb - ref).abs().max()) <= tol, (n, rep)
+        if rep == 0:                                                   # a second backward accumulates on both sides
+            run(ma)
+            run(mb)
