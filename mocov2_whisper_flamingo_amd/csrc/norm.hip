@@ -252,6 +252,50 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
     }
 }
 
+// Both steps in one launch for up to a few thousand slab rows: one 1024-thread workgroup per 64 channels,
+// its 16 waves sum interleaved rows (16 loads in flight per lane), fold through LDS in a fixed order
+// (deterministic) and the first wave finalises.  Saves a launch per batch-norm layer.
+#define BN_FUSED_MAX_PARTS 8192
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq,
+                                                                  int nparts, float count, const float* __restrict__ weight,
+                                                                  const float* __restrict__ bias, float* __restrict__ running_mean,
+                                                                  float* __restrict__ running_var, float* __restrict__ scale,
+                                                                  float* __restrict__ shift, int C, float eps, float momentum) {
+    __shared__ float red[2][16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int cc = min(c, C - 1);
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[u] = 0.f; b[u] = 0.f; }
+    int p = w;
+    for (; p + 16 * 7 < nparts; p += 16 * 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] += sum[(long)(p + 16 * u) * C + cc];
+            b[u] += sumsq[(long)(p + 16 * u) * C + cc];
+        }
+    }
+    for (; p < nparts; p += 16) { a[0] += sum[(long)p * C + cc]; b[0] += sumsq[(long)p * C + cc]; }
+    red[0][w][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    red[1][w][lane] = ((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]));
+    __syncthreads();
+    if (w != 0 || c >= C) return;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s += red[0][i][lane]; q += red[1][i][lane]; }
+    const float mean = s / count;
+    const float var = fmaxf(q / count - mean * mean, 0.f);
+    const float sc = weight[c] * rsqrtf(var + eps);
+    scale[c] = sc;
+    shift[c] = bias[c] - mean * sc;
+    if (running_mean) {
+        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+}
+
 // Eval-mode fold: scale = w / sqrt(running_var + eps), shift = b - running_mean*scale.
 __global__ void bn_fold_kernel(const float* __restrict__ weight, const float* __restrict__ bias,
                                const float* __restrict__ running_mean, const float* __restrict__ running_var,
@@ -296,7 +340,10 @@ extern "C" int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const fl
     if (!sum || !sumsq || !weight || !bias || !scale || !shift || C <= 0 || count <= 0 || nparts <= 0) return AVSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const dim3 fgrid((unsigned)((C + 255) / 256)), fblock(256);
-    if (nparts > BN_RED_PARTS) {
+    if (nparts > BN_RED_PARTS && nparts <= BN_FUSED_MAX_PARTS) {
+        hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, s, sum, sumsq, (int)nparts,
+                           (float)count, weight, bias, running_mean, running_var, scale, shift, (int)C, eps, momentum);
+    } else if (nparts > BN_RED_PARTS) {
         if (!ws) return AVSR_EINVAL;
         hipLaunchKernelGGL(bn_reduce_parts_kernel, dim3((unsigned)((C + 63) / 64), BN_RED_PARTS), dim3(256), 0, s, sum, sumsq,
                            (int)nparts, (int)C, ws);

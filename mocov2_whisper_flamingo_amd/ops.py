@@ -321,7 +321,7 @@ def bn_finalize(col_sum, col_sumsq, count, weight, bias, running_mean, running_v
     C = weight.numel()
     nparts = col_sum.numel() // C
     ws = None
-    if nparts > 32:
+    if nparts > 8192:          # beyond the single-launch kernel's range: two-stage reduction needs a workspace
         ws = torch.empty(lib.avsr_bn_finalize_workspace_floats(C), dtype=torch.float32, device=weight.device)
     check(lib.avsr_bn_finalize(_stream(), col_sum.data_ptr(), col_sumsq.data_ptr(), nparts, float(count), weight.data_ptr(),
                                bias.data_ptr(), _p(running_mean), _p(running_var), scale.data_ptr(), shift.data_ptr(),

@@ -277,6 +277,29 @@ def test_stem_mfma(dev, H, W, train):
     assert rel_err(y, y2) < 2e-2
 
 
+@pytest.mark.parametrize("nparts,C", [(5, 64), (33, 100), (793, 128), (2930, 64), (9000, 256)])
+def test_bn_finalize_slabs(dev, nparts, C):
+    """Training-mode BN statistics from [parts, C] partial-sum slabs (direct, single-launch and two-stage paths)."""
+    g = torch.Generator().manual_seed(nparts)
+    rows_per_part = 16
+    x = torch.randn(nparts * rows_per_part, C, generator=g) * 2 + 0.5
+    xs = x.view(nparts, rows_per_part, C)
+    s1, s2 = xs.sum(1), (xs * xs).sum(1)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(w); bn.bias.copy_(b); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.train()
+    ref = bn(x)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    sc, sh = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    ops.bn_finalize(s1.to(dev), s2.to(dev), x.shape[0], w.to(dev), b.to(dev), rmd, rvd, sc, sh)
+    got = x * sc.cpu() + sh.cpu()
+    assert rel_err(got, ref) < 2e-4
+    assert rel_err(rmd, bn.running_mean) < 1e-4 and rel_err(rvd, bn.running_var) < 1e-4
+
+
 @pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
 def test_stem_pool_bn(dev, odt):
     g = torch.Generator().manual_seed(5)
