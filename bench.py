@@ -147,8 +147,10 @@ def main():
     roofline = None
     if not args.no_roofline and rank == 0:
         ops.GEMM_PROFILE = []
+        model.overlap_encoders = False     # per-launch durations of the kernel alone: no second stream sharing the CUs
         step()
         torch.cuda.synchronize()
+        model.overlap_encoders = True
         recs = [(a.elapsed_time(b) * 1e-3, fl) for a, b, fl, tag, *_rest in ops.GEMM_PROFILE if tag == "bf16"]
         ops.GEMM_PROFILE = None
         tsum, fsum = sum(r[0] for r in recs), sum(r[1] for r in recs)

@@ -69,6 +69,8 @@ class AVNet(nn.Module):
 
         self._cache = Fn.WeightCache(dtype)
         self._seed, self._step = int(seed), 0
+        self.overlap_encoders = True        # run the visual frontend on a second stream next to the audio encoder
+        self._side = None
         self.fusion_module.set_runtime(self._cache, self._dropout_seed)
         if device is not None:
             self.to(device)
@@ -78,6 +80,13 @@ class AVNet(nn.Module):
         """A distinct 64-bit stream id per (construction seed, forward call, site)."""
         mix = self._seed * 0x9E3779B97F4A7C15 + self._step * 0xBF58476D1CE4E5B9 + zlib.crc32(tag.encode())
         return mix & 0xFFFFFFFFFFFFFFFF
+
+    @property
+    def _side_stream(self):
+        dev = torch.cuda.current_device()
+        if self._side is None or self._side[0] != dev:
+            self._side = (dev, torch.cuda.Stream(device=dev))
+        return self._side[1]
 
     def make_padding_mask(self, lengths, max_length):
         """True = padded position (models/av_net.py:111-114)."""
@@ -93,9 +102,20 @@ class AVNet(nn.Module):
         self._step += 1
         # AUDIO: [B,3000,80] is already channels-last, the layout the conv kernel wants
         channels_last = audioBatch.shape[1] == 3000 and audioBatch.shape[2] == 80
+        # The two frozen encoders are independent until the fusion: the visual frontend runs on a second HIP
+        # stream so its many short kernels fill the CUs the audio encoder's GEMM tails leave idle (and vice versa).
+        main = torch.cuda.current_stream()
+        side = self._side_stream if self.overlap_encoders else None
+        if side is not None:
+            side.wait_stream(main)                                          # the inputs are ready on `main`
+            with torch.cuda.stream(side):
+                vis = self.visual_model(videoBatch, videoLen)               # [B,Tv,2048]
         enc = self.whisper_model.encoder(audioBatch, attention_mask=None, dtype=cdt, channels_last=channels_last)[0]
-        # VIDEO
-        vis = self.visual_model(videoBatch, videoLen)                       # [B,Tv,2048]
+        if side is not None:
+            main.wait_stream(side)
+            vis.record_stream(main)
+        else:
+            vis = self.visual_model(videoBatch, videoLen)                   # [B,Tv,2048]
         B, Ta, D = enc.shape
         Tv = vis.shape[1]
         min_len = min(Ta, Tv)

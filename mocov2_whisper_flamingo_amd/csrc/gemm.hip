@@ -147,10 +147,12 @@ __device__ __forceinline__ void stats_quad(const GemmP& p, f32x4 s, f32x4 s2, in
 // costs several scalar branches per element) and the row loop is NOT unrolled: the epilogue runs once per
 // tile, so its instructions are fetched cold, and straight-line code four times as long measured 17-30 %
 // slower on the K = 768 encoder GEMMs (instruction-cache misses, not arithmetic).
-template <int BN_, typename OutT, int ACT, bool CONV>
-__device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[4][BN_ / 32], char* lds, const float* sb,
+template <int BN_, typename OutT, int ACT, bool CONV, int MI>
+__device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][BN_ / 32], char* lds, const float* sb,
                                               int m0, int n0, int tm, long cbase, int lane, int wave) {
     constexpr int NJ = BN_ / 32, LDT = BN_ + 4, CG = BN_ / 8, RS = 256 / CG;
+    // a pass moves SUBS 16-row sub-tiles of each wave (2 x SUBS x 16 tile rows) through the LDS tile
+    constexpr int SUBS = (MI % 2 == 0) ? 2 : 1, NPASS = MI / SUBS, PROWS = 2 * SUBS * 16;
     float* Ct = (float*)lds;
     float* red = Ct + 64 * LDT;                 // [4][2][BN_] per-wave column partials
     const int wm = wave >> 1, wn = wave & 1;
@@ -171,18 +173,20 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[4][BN
     const bool has_res = p.res != nullptr;
     const bool stats = p.csum != nullptr;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NPASS; ++h) {
         __syncthreads();
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < SUBS; ++ii)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                *(f32x4*)&Ct[(wm * 32 + ii * 16 + (lane & 15)) * LDT + (wn * NJ + j) * 16 + (lane >> 4) * 4] = acc[2 * h + ii][j];
+                *(f32x4*)&Ct[(wm * SUBS * 16 + ii * 16 + (lane & 15)) * LDT + (wn * NJ + j) * 16 + (lane >> 4) * 4] =
+                    acc[SUBS * h + ii][j];
         __syncthreads();
 #pragma unroll 1
-        for (int it = 0; it < 64 / RS; ++it) {
+        for (int it = 0; it < (PROWS + RS - 1) / RS; ++it) {
             const int lr = r0 + it * RS;
-            const int m = m0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+            if (PROWS % RS != 0 && lr >= PROWS) continue;
+            const int m = m0 + (lr / (SUBS * 16)) * (MI * 16) + h * (SUBS * 16) + (lr % (SUBS * 16));
             if (m >= p.M) continue;
             const f32x4 c0 = *(const f32x4*)&Ct[lr * LDT + cg * 8], c1 = *(const f32x4*)&Ct[lr * LDT + cg * 8 + 4];
             float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -259,15 +263,15 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[4][BN
     }
 }
 
-template <int BN_, typename OutT, bool CONV>
-__device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[4][BN_ / 32], char* lds, const float* sb,
+template <int BN_, typename OutT, bool CONV, int MI>
+__device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][BN_ / 32], char* lds, const float* sb,
                                               int m0, int n0, int tm, long cbase, int lane, int wave) {
     switch (p.act) {                            // block-uniform
-        case AVSR_ACT_GELU: epilogue_body<BN_, OutT, AVSR_ACT_GELU, CONV>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
-        case AVSR_ACT_RELU: epilogue_body<BN_, OutT, AVSR_ACT_RELU, CONV>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
+        case AVSR_ACT_GELU: epilogue_body<BN_, OutT, AVSR_ACT_GELU, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
+        case AVSR_ACT_RELU: epilogue_body<BN_, OutT, AVSR_ACT_RELU, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
         case AVSR_ACT_RELU_AFTER_RESIDUAL:
-            epilogue_body<BN_, OutT, AVSR_ACT_RELU_AFTER_RESIDUAL, CONV>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
-        default: epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
+            epilogue_body<BN_, OutT, AVSR_ACT_RELU_AFTER_RESIDUAL, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
+        default: epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
     }
 }
 
@@ -295,6 +299,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[4][BN
 #ifndef G_NST_SWITCH_TILES
 #define G_NST_SWITCH_TILES 500
 #endif
+#define G_NUM_CU 256
 #ifndef G_DEEP_TILES
 #define G_DEEP_TILES 256
 #endif
@@ -324,15 +329,17 @@ extern "C" int avsr_debug_read_stamps(unsigned long long* out) {
 #define STAMP(i)
 #endif
 
-template <int BN_, int G_NST> constexpr int gemm_lds_bytes() {
-    constexpr int stage = (G_BM / 8 + BN_ / 8) * 1024;
+template <int BN_, int G_NST, int BM_ = G_BM> constexpr int gemm_lds_bytes() {
+    constexpr int stage = (BM_ / 8 + BN_ / 8) * 1024;
     constexpr int epi = (64 * (BN_ + 4) + 8 * BN_) * 4;
     return (G_NST * stage > epi ? G_NST * stage : epi) + 2 * BN_ * 4;     // + the tile's scale / bias columns
 }
 
-template <int BN_, int G_NST, bool CONV, typename OutT>
+template <int BN_, int G_NST, bool CONV, typename OutT, int BM_ = G_BM>
 __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(GemmP p) {
-    constexpr int APIECES = G_BM / 8, BPIECES = BN_ / 8;      // 1-KiB pieces (8 rows x 128 B)
+    static_assert(BM_ % 32 == 0 && (BM_ == G_BM || !CONV), "row tile: 4 x whole pieces per wave; conv cursors assume 128");
+    constexpr int MI = BM_ / 32;                              // 16-row sub-tiles per wave (two waves stacked in M)
+    constexpr int APIECES = BM_ / 8, BPIECES = BN_ / 8;       // 1-KiB pieces (8 rows x 128 B)
     constexpr int STAGE_BYTES = (APIECES + BPIECES) * 1024;
     constexpr int NJ = BN_ / 32;            // 16-column sub-tiles per wave
     constexpr int NAL = APIECES / 4, NBL = BPIECES / 4;       // pieces each wave loads per K-step
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(Ge
 
     int tm, tn;
     tile_coords(p, tm, tn);
-    const int m0 = tm * G_BM, n0 = tn * BN_;
+    const int m0 = tm * BM_, n0 = tn * BN_;
     const int bz = blockIdx.z;
     const bf16_t* A = (const bf16_t*)p.A + (long)bz * p.sA;
     const bf16_t* B = (const bf16_t*)p.B + (long)bz * p.sB;
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(Ge
     const int wm = wave >> 1, wn = wave & 1;
 
     // alpha * scale[n] and bias[n] of the tile's columns go to LDS now, so the epilogue does not wait on them
-    float* sb = (float*)(lds + gemm_lds_bytes<BN_, G_NST>() - 2 * BN_ * 4);
+    float* sb = (float*)(lds + gemm_lds_bytes<BN_, G_NST, BM_>() - 2 * BN_ * 4);
     if (t < BN_) {
         const int nc = min(n0 + t, p.N - 1);
         sb[t] = p.scale ? p.scale[nc] * p.alpha : p.alpha;
@@ -380,7 +387,8 @@ __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(Ge
         if constexpr (CONV) { crow[q] = conv_row(p, m); baseA[q] = 0; stepA[q] = 0; }
         else {
             const long live = -(long)(m < p.M);
-            baseA[q] = zaddr + (((uintptr_t)(A + (long)m * p.lda + kofs[q & 1]) - zaddr) & (uintptr_t)live);
+            const int ko = ((NAL * wave + q) & 1) ? kofs[1] : kofs[0];      // swizzle follows the piece's row parity
+            baseA[q] = zaddr + (((uintptr_t)(A + (long)m * p.lda + ko) - zaddr) & (uintptr_t)live);
             stepA[q] = (long)(G_BK * sizeof(bf16_t)) & live;
         }
     }
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(Ge
                 a = zaddr + ((real - zaddr) & kin[q & 1] & (uintptr_t)(-(long)ok));
             } else {
                 a = baseA[q] + (uintptr_t)((long)ks * stepA[q]);
-                if (ktail) a = zaddr + ((a - zaddr) & kin[q & 1]);
+                if (ktail) a = zaddr + ((a - zaddr) & kin[(NAL * wave + q) & 1]);
             }
             __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (NAL * wave + q) * 1024), 16, 0, 0);
         }
@@ -441,9 +449,9 @@ __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(Ge
         }
     };
 
-    f32x4 acc[4][NJ];
+    f32x4 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -454,14 +462,14 @@ __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(Ge
     auto compute = [&](const char* st, int kt) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 xf[4], wf[NJ];
+            bf16x8 xf[MI], wf[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(st + (wm * 4 + i) * 2048 + frow + fpos[ks]);
+            for (int i = 0; i < MI; ++i) xf[i] = *(const bf16x8*)(st + (wm * MI + i) * 2048 + frow + fpos[ks]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) wf[j] = *(const bf16x8*)(st + APIECES * 1024 + (wn * NJ + j) * 2048 + frow + fpos[ks]);
             if (G_NST > 1 && ks == 0) issue(kt + G_NST - 1);   // refill the stage the previous step used
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
@@ -494,14 +502,14 @@ __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(Ge
         wait_vmcnt<0>();                        // drain the re-loaded steps before the LDS is reused
     }
     STAMP(3);
-    epilogue_tile<BN_, OutT, CONV>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+    epilogue_tile<BN_, OutT, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
 #ifdef GEMM_STAMPS
     STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(5);
 #ifdef GEMM_STAMPS_TWICE
     __syncthreads();
-    epilogue_tile<BN_, OutT, CONV>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+    epilogue_tile<BN_, OutT, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
     STAMP(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(7);
@@ -644,7 +652,19 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
                (!g->residual || (((g->ldr * osz) % 16 == 0) && aligned_to(g->residual, 16)));
     if ((g->residual || g->col_sum) && g->batch > 1) return AVSR_EUNSUPPORTED;
     const int bn = (bf && g->N <= 64) ? 64 : 128;
-    const int tmS = bf ? G_BM : FM, tnS = bf ? bn : FN;
+    // Row tile: 128, or 96 where that fills the CUs' last round much better (M = 12000, N = 768: 564 tiles leave a
+    // quarter of the chip idle while 52 CUs run a third tile; 750 tiles of 96 rows are 2.93 per CU).
+    int bm = G_BM;
+    if (bf && !conv && !g->col_sum && bn == 128 && g->batch == 1) {
+        const long tn = (p.N + 127) / 128;
+        const long t128 = ((p.M + 127) / 128) * tn, t96 = ((p.M + 95) / 96) * tn;
+        auto fill = [](long t, long rows, long M, long tnn) {      // useful rows / rows the busiest CU's rounds pay for
+            const long rounds = (t + G_NUM_CU - 1) / G_NUM_CU;
+            return (double)M * tnn / ((double)rounds * G_NUM_CU * rows);
+        };
+        if (t96 >= G_NST_SWITCH_TILES && fill(t96, 96, p.M, tn) > 1.12 * fill(t128, 128, p.M, tn)) bm = 96;
+    }
+    const int tmS = bf ? bm : FM, tnS = bf ? bn : FN;
     p.tiles_m = (p.M + tmS - 1) / tmS;
     p.tiles_n = (p.N + tnS - 1) / tnS;
     const long ntiles = (long)p.tiles_m * p.tiles_n;
@@ -665,6 +685,18 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         }                                                                                                      \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
     } while (0)
+#define LAUNCHBM(BNV, NSTV, OT, BMV)                                                                           \
+    do {                                                                                                       \
+        static bool attr_set = false;                                                                          \
+        constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV, BMV>();                                            \
+        auto kfn = gemm_bf16_kernel<BNV, NSTV, false, OT, BMV>;                                                \
+        if (!attr_set) {                                                                                       \
+            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)   \
+                != hipSuccess) return AVSR_EHIP;                                                               \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
+    } while (0)
 #define LAUNCH_CV_OT(BNV, NSTV)                                                                                \
     do {                                                                                                       \
         if (conv) { if (of) LAUNCHB(BNV, NSTV, true, float); else LAUNCHB(BNV, NSTV, true, bf16_t); }          \
@@ -672,7 +704,9 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     } while (0)
     if (bf) {
         const bool single = ntiles * g->batch >= G_NST_SWITCH_TILES;
-        if (!conv && bn == 128 && ntiles * g->batch <= G_DEEP_TILES) {     // at most one workgroup per CU: 3 K-steps in flight
+        if (bm == 96) {
+            if (of) LAUNCHBM(128, 1, float, 96); else LAUNCHBM(128, 1, bf16_t, 96);
+        } else if (!conv && bn == 128 && ntiles * g->batch <= G_DEEP_TILES) {     // at most one workgroup per CU: 3 K-steps in flight
             if (of) LAUNCHB(128, 4, false, float); else LAUNCHB(128, 4, false, bf16_t);
         } else if (bn == 64) { if (single) LAUNCH_CV_OT(64, 1); else LAUNCH_CV_OT(64, 2); }
         else          { if (single) LAUNCH_CV_OT(128, 1); else LAUNCH_CV_OT(128, 2); }
@@ -682,6 +716,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     }
 #undef LAUNCH
 #undef LAUNCHB
+#undef LAUNCHBM
 #undef LAUNCH_CV_OT
     return avsr_launch_status();
 }

@@ -30,6 +30,29 @@ def rnd(gen, *shape, dtype=torch.float32, scale=1.0):
     return x.to(dtype).float() if dtype == torch.bfloat16 else x
 
 
+@pytest.mark.parametrize("M,N,K,odt", [(12000, 768, 768, torch.float32), (11990, 700, 264, torch.bfloat16),
+                                       (12000, 768, 3072, torch.float32)])
+def test_gemm_row_tile_96(dev, M, N, K, odt):
+    """Shapes for which the host picks the 96-row tile (fills the last round of workgroups better): bias + GELU
+    (bf16 out) or bias + in-place fp32 residual, ragged M / N / K included."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = rnd(g, M, K, dtype=torch.bfloat16), rnd(g, N, K, dtype=torch.bfloat16, scale=0.05)
+    bias = torch.randn(N, generator=g)
+    ref = a @ b.T + bias
+    ld = (N + 7) // 8 * 8
+    if odt == torch.float32:
+        res = torch.randn(M, N, generator=g)
+        ref = res + ref
+        buf = torch.zeros(M, ld, device=dev)
+        buf[:, :N] = res.to(dev)
+        out = ops.gemm_nt(a.to(dev, torch.bfloat16), b.to(dev, torch.bfloat16), out=buf[:, :N], bias=bias.to(dev),
+                          residual=buf[:, :N])
+    else:
+        ref = F.gelu(ref)
+        out = ops.gemm_nt(a.to(dev, torch.bfloat16), b.to(dev, torch.bfloat16), bias=bias.to(dev), act=ops.ACT_GELU)
+    assert rel_err(out, ref) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 64), (128, 128, 128), (257, 1001, 512), (75, 2048, 520), (1, 64, 8)])
 def test_gemm_plain(dev, dtype, M, N, K):
