@@ -88,6 +88,10 @@ class FlatTrainer:
         self._works = []
         # the backward kernels accumulate straight into the flat gradient buffer (functional.grad_sink);
         # gradients that still arrive through autograd keep the ordinary post-accumulate hook
+        # ... on a stream of their own, beside the dX chain of backward
+        self.grad_stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
+        from . import functional as Fn
+        Fn.GRAD_STREAM = self.grad_stream
         for _, p in self.named:
             p._avsr_direct_grad = self.on_gpu
             p._avsr_grad_hook = self._on_grad_ready if self.overlap else None
@@ -107,6 +111,8 @@ class FlatTrainer:
         view = self.flat_grad[lo:hi]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            if self.grad_stream is not None:
+                self.comm_stream.wait_stream(self.grad_stream)
             with torch.cuda.stream(self.comm_stream):
                 w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
@@ -120,6 +126,7 @@ class FlatTrainer:
             self._reduce_bucket(b)
 
     def zero_grad(self):
+        self.join_gradients()
         self.flat_grad.zero_()
         for n, p in self.named:          # keep .grad pointing into the flat buffer
             if p.grad is None:
@@ -130,6 +137,7 @@ class FlatTrainer:
     def reduce_gradients(self):
         """Finish the all-reduce of every bucket (launching those the hooks did not) and
         turn the sums into means."""
+        self.join_gradients()
         if self.world == 1:
             return
         for b in self.buckets:
@@ -142,9 +150,15 @@ class FlatTrainer:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.flat_grad.mul_(1.0 / self.world)
 
+    def join_gradients(self):
+        """Make the current stream wait for the parameter-gradient kernels queued on ``grad_stream``."""
+        if self.grad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.grad_stream)
+
     # ---- optimizer ----------------------------------------------------------
     def step(self, lr=None):
         """Global-norm clip (train.py:321) + AdamW (train.py:219-225) on the flat buffers."""
+        self.join_gradients()
         self.step_count += 1
         lr = self.lr if lr is None else lr
         scr = self._scratch

@@ -75,9 +75,27 @@ def grad_done(p, parts=1):
     hook(p)
 
 
+# Stream for parameter-gradient work that goes straight into sink buffers: it is off the critical path of
+# backward (only dX feeds the next node), so it can run beside it.  Set by the gradient buffers' owner, who
+# must make its own stream wait for this one before reading the gradients (dp.FlatTrainer does both).
+GRAD_STREAM = None
+
+
 def _param_grads(dy, x, has_bias, sink):
     """dW = dY^T X and db = column sums of dY: returned, or accumulated into the sink buffers."""
     pw, pb, rows, parts = sink if sink is not None else (None, None, None, 1)
+    gs = GRAD_STREAM
+    if gs is not None and grad_sink(pw, rows) is not None and (not has_bias or grad_sink(pb, rows) is not None):
+        main = torch.cuda.current_stream()
+        gs.wait_stream(main)                                # dy and x are complete on the backward stream
+        dy.record_stream(gs)
+        x.record_stream(gs)
+        with torch.cuda.stream(gs):
+            return _param_grads_here(dy, x, has_bias, pw, pb, rows, parts)
+    return _param_grads_here(dy, x, has_bias, pw, pb, rows, parts)
+
+
+def _param_grads_here(dy, x, has_bias, pw, pb, rows, parts):
     dyt = ops.transpose2d(dy, pad_to=8)                     # [N, Mp]
     xt = ops.transpose2d(x, pad_to=8)                       # [K, Mp]
     gw = grad_sink(pw, rows)

@@ -329,6 +329,7 @@ def test_flat_trainer_direct_gradients_match_autograd(dev, dtype):
     assert torch.allclose(la, lb, rtol=1e-6, atol=1e-6)
     named_a = dict(trainable_parameters(ma))
     for rep in range(2):
+        tr.join_gradients()                    # parameter gradients are produced on the trainer's own stream
         for n, p in trainable_parameters(mb):
             ga, gb = named_a[n].grad, p.grad
             assert ga is not None and gb is not None, n
