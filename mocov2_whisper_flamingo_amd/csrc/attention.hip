@@ -59,13 +59,20 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
                                                             long ldk, const bf16_t* __restrict__ V, long ldv,
                                                             bf16_t* __restrict__ O, long ldo, const uint8_t* __restrict__ mask,
                                                             float* __restrict__ lse, int Tq, int Tk, int H, float scale,
-                                                            float pdrop, uint64_t seed) {
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * 64];
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * 64];
-    const int b = blockIdx.z, h = blockIdx.y;
+                                                            float pdrop, uint64_t seed, int B) {
+    __shared__ __attribute__((aligned(16))) bf16_t Kbuf[2][64 * 64];      // double-buffered: one barrier per key tile
+    __shared__ __attribute__((aligned(16))) bf16_t Vbuf[2][64 * 64];
+    // 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs (id % 8), each with its own L2.  All
+    // query tiles of one (batch, head) are given to ONE XCD so its K/V are fetched from the fabric once, not 8 times.
+    const int qtiles = (Tq + 127) >> 7, npairs = B * H;
+    const int per_xcd = (npairs + 7) >> 3;                         // grid = 8 * per_xcd * qtiles workgroups
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = xcd * per_xcd + slot / qtiles, qt = slot - (slot / qtiles) * qtiles;
+    if (pair >= npairs || slot >= per_xcd * qtiles) return;
+    const int b = pair / H, h = pair - b * H;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r = lane & 31, hf = lane >> 5;
-    const int q = blockIdx.x * 128 + wave * 32 + r;          // this lane's query row
+    const int q = qt * 128 + wave * 32 + r;                   // this lane's query row
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     bf16x8 qf[4];
@@ -99,16 +106,21 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
             vreg[i] = ok ? *(const bf16x8*)(Vb + (long)key * ldv + lc * 8) : zero8;
         }
     };
-    prefetch(0);
-    for (int kv0 = 0; kv0 < Tk; kv0 += 64) {
-        __syncthreads();                                      // previous tile fully consumed
+    auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *(bf16x8*)&Ks[k_off(lr + 32 * i, lc)] = kreg[i];
-            *(bf16x8*)&Vs[v_off(lr + 32 * i, lc)] = vreg[i];
+            *(bf16x8*)&Kbuf[buf][k_off(lr + 32 * i, lc)] = kreg[i];
+            *(bf16x8*)&Vbuf[buf][v_off(lr + 32 * i, lc)] = vreg[i];
         }
-        __syncthreads();
-        if (kv0 + 64 < Tk) prefetch(kv0 + 64);
+    };
+    prefetch(0);
+    stage(0);
+    __syncthreads();
+    for (int kv0 = 0, cur = 0; kv0 < Tk; kv0 += 64, cur ^= 1) {
+        const bf16_t* Ks = Kbuf[cur];
+        const bf16_t* Vs = Vbuf[cur];
+        const bool more = kv0 + 64 < Tk;
+        if (more) prefetch(kv0 + 64);                         // lands in registers while this tile is computed
 
         f32x16 sacc[2];
 #pragma unroll
@@ -175,6 +187,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
                 for (int db = 0; db < 2; ++db)
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr_frag(Vs, st, s2, db, lane), pf, oacc[db], 0, 0, 0);
             }
+        if (more) stage(cur ^ 1);                             // the other buffer was last read one barrier ago
+        __syncthreads();
     }
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
@@ -642,15 +656,16 @@ extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, cons
         if (p_drop < 0.f || p_drop >= 1.f) return AVSR_EINVAL;
         if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return AVSR_EUNSUPPORTED;
         if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) % 16 || (uintptr_t)O % 8) return AVSR_EUNSUPPORTED;
-        dim3 grid((unsigned)((Tq + 127) / 128), (unsigned)H, (unsigned)B);
+        if (B * H * ((Tq + 127) / 128) > 0x3fffffff) return AVSR_EUNSUPPORTED;
+        dim3 grid((unsigned)(8 * ((B * H + 7) / 8) * ((Tq + 127) / 128)));
         if (p_drop > 0.f)
             hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                                (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
-                               (int)Tq, (int)Tk, (int)H, scale, p_drop, seed);
+                               (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, (int)B);
         else
             hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                                (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
-                               (int)Tq, (int)Tk, (int)H, scale, 0.f, seed);
+                               (int)Tq, (int)Tk, (int)H, scale, 0.f, seed, (int)B);
         return avsr_launch_status();
     }
     dim3 grid((unsigned)((Tq + 31) / 32), (unsigned)H, (unsigned)B);
