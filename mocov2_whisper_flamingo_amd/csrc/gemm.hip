@@ -309,6 +309,18 @@ __device__ __attribute__((aligned(16))) unsigned int avsr_zero_page[4] = {0u, 0u
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// One LDS-DMA piece from a UNIFORM base (scalar register pair) plus a 32-bit per-lane byte offset: the
+// saddr form of the instruction, which the builtin does not select (it re-associates the sum into a 64-bit
+// per-lane pointer and pays a 64-bit vector add per piece and K-step).  M0 carries the LDS destination and is
+// compiler-reserved: saved and restored inside the statement.  The compiler does not count this load: every
+// user waits with an explicit s_waitcnt vmcnt before the barrier that publishes the stage.
+__device__ __forceinline__ void dma_piece(const char* sbase, unsigned voff, const char* lds_dst) {
+    unsigned keep;
+    const unsigned ldsa = (unsigned)(uintptr_t)(lptr_t)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(ldsa) : "memory");
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -369,82 +381,102 @@ __global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(Ge
         sb[BN_ + t] = p.bias ? p.bias[nc] : 0.f;
     }
 
-    // ---- per-lane DMA sources -------------------------------------------------
-    // Piece q of this wave covers rows 8*(4*wave+q) .. +7; lane i fetches row i>>3, source chunk
-    // (i&7) ^ swz with swz = ((row >> 1) & 7) = 4*(q&1) + (i>>4): two distinct k offsets per lane.
-    // Address selection is pure integer arithmetic (zero + ((real - zero) & mask)): a ?: on the
-    // pointer lets the compiler branch around the DMA, and every wave must issue exactly LPT DMA
-    // instructions per step for the counted wait to mean anything.
+    // ---- DMA sources ----------------------------------------------------------
+    // Piece q of this wave covers rows 8*(NAL*wave+q) .. +7; lane i fetches row i>>3, source chunk
+    // (i&7) ^ swz with swz = ((row >> 1) & 7) = 4*(piece&1) + (i>>4): two distinct k offsets per lane.
+    // Dense operands: a uniform tile base (scalar registers) plus a 32-bit per-lane byte offset that never
+    // changes - a K-step only moves the scalar base, so the loop carries no 64-bit vector address arithmetic.
+    // Rows past M / N are clamped onto the last valid row (their products are never stored).  Only the K tail
+    // of the last step, and the conv taps that fall into the padding, read a 16-byte zero page; there the
+    // address is selected with integer arithmetic (zero + ((real - zero) & mask)): a ?: on the pointer lets
+    // the compiler branch around the DMA, and every wave must issue exactly LPT DMA instructions per step
+    // for the counted wait to mean anything.
     const uintptr_t zaddr = (uintptr_t)avsr_zero_page;
     const int kofs[2] = {(((lane & 7) ^ (lane >> 4)) * 8), (((lane & 7) ^ (4 + (lane >> 4))) * 8)};
-    uintptr_t baseA[NAL];
-    long stepA[NAL];
+    const char* tileA = (const char*)(A + (long)m0 * p.lda);
+    const char* tileB = (const char*)(B + (long)n0 * p.ldb);
+    unsigned offA[NAL], offB[NBL];
     ConvRow crow[NAL];
     int kh[2] = {0, 0}, kw[2] = {0, 0}, cc[2] = {0, 0};
 #pragma unroll
     for (int q = 0; q < NAL; ++q) {
-        const int m = m0 + (NAL * wave + q) * 8 + (lane >> 3);
-        if constexpr (CONV) { crow[q] = conv_row(p, m); baseA[q] = 0; stepA[q] = 0; }
+        const int r = (NAL * wave + q) * 8 + (lane >> 3);
+        if constexpr (CONV) { crow[q] = conv_row(p, m0 + r); offA[q] = 0; }
         else {
-            const long live = -(long)(m < p.M);
             const int ko = ((NAL * wave + q) & 1) ? kofs[1] : kofs[0];      // swizzle follows the piece's row parity
-            baseA[q] = zaddr + (((uintptr_t)(A + (long)m * p.lda + ko) - zaddr) & (uintptr_t)live);
-            stepA[q] = (long)(G_BK * sizeof(bf16_t)) & live;
+            offA[q] = (unsigned)(((long)min(r, p.M - 1 - m0) * p.lda + ko) * (long)sizeof(bf16_t));
         }
     }
     if constexpr (CONV) {
         conv_col(p, kofs[0], kh[0], kw[0], cc[0]);
         conv_col(p, kofs[1], kh[1], kw[1], cc[1]);
     }
-    uintptr_t baseB[NBL];
-    long stepB[NBL];
 #pragma unroll
     for (int q = 0; q < NBL; ++q) {
-        const int n = n0 + (NBL * wave + q) * 8 + (lane >> 3);
-        const long live = -(long)(n < p.N);
-        baseB[q] = zaddr + (((uintptr_t)(B + (long)n * p.ldb + kofs[q & 1]) - zaddr) & (uintptr_t)live);
-        stepB[q] = (long)(G_BK * sizeof(bf16_t)) & live;
+        const int r = (NBL * wave + q) * 8 + (lane >> 3);
+        offB[q] = (unsigned)(((long)min(r, p.N - 1 - n0) * p.ldb + kofs[q & 1]) * (long)sizeof(bf16_t));
     }
     const int nk = (p.K + G_BK - 1) / G_BK;
-
-    // K a multiple of the K-step: no per-lane K-tail mask is needed, and steps past the last one simply
-    // re-load the last real step into a stage nobody reads any more (keeps the wait count constant).
     const bool ktail = (p.K % G_BK) != 0;
+
+    // Steps past the last one re-load the last real step into a stage nobody reads any more (keeps the wait
+    // count constant).
     auto issue = [&](int kt) {              // DMA the operands of K-step kt into stage kt % G_NST
         char* st = lds + (kt % G_NST) * STAGE_BYTES;
-        const int ks = ktail ? kt : min(kt, nk - 1);
-        uintptr_t kin[2] = {~(uintptr_t)0, ~(uintptr_t)0};
-        if (ktail) {
-            kin[0] = (uintptr_t)(-(long)(kt * G_BK + kofs[0] < p.K));
-            kin[1] = (uintptr_t)(-(long)(kt * G_BK + kofs[1] < p.K));
-        }
+        const int ks = min(kt, nk - 1);
+        const bool tail = ktail && ks == nk - 1;                            // workgroup-uniform
+        const long kbytes = (long)ks * (G_BK * (long)sizeof(bf16_t));
+        if constexpr (CONV) {
+            uintptr_t kin[2] = {~(uintptr_t)0, ~(uintptr_t)0};
+            if (ktail) {
+                kin[0] = (uintptr_t)(-(long)(kt * G_BK + kofs[0] < p.K));
+                kin[1] = (uintptr_t)(-(long)(kt * G_BK + kofs[1] < p.K));
+            }
 #pragma unroll
-        for (int q = 0; q < NAL; ++q) {
-            uintptr_t a;
-            if constexpr (CONV) {
+            for (int q = 0; q < NAL; ++q) {
                 const int ih = crow[q].ih0 + kh[q & 1], iw = crow[q].iw0 + kw[q & 1];
                 const bool ok = crow[q].ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
                 const uintptr_t real = (uintptr_t)(A + ((long)(crow[q].base + ih * p.W + iw)) * p.Cc + cc[q & 1]);
-                a = zaddr + ((real - zaddr) & kin[q & 1] & (uintptr_t)(-(long)ok));
-            } else {
-                a = baseA[q] + (uintptr_t)((long)ks * stepA[q]);
-                if (ktail) a = zaddr + ((a - zaddr) & kin[(NAL * wave + q) & 1]);
+                const uintptr_t a = zaddr + ((real - zaddr) & kin[q & 1] & (uintptr_t)(-(long)ok));
+                __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (NAL * wave + q) * 1024), 16, 0, 0);
             }
-            __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (NAL * wave + q) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < NBL; ++q) {
-            uintptr_t a = baseB[q] + (uintptr_t)((long)ks * stepB[q]);
-            if (ktail) a = zaddr + ((a - zaddr) & kin[q & 1]);
-            __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (APIECES + NBL * wave + q) * 1024), 16, 0, 0);
-        }
-        if constexpr (CONV) {               // advance the two (tap, channel) cursors by one K-step
-            if (ktail || kt < nk - 1) {
+            if (ktail || kt < nk - 1) {     // advance the two (tap, channel) cursors by one K-step
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     cc[e] += G_BK;
                     while (cc[e] >= p.Cc) { cc[e] -= p.Cc; if (++kw[e] == p.KW) { kw[e] = 0; ++kh[e]; } }
                 }
+            }
+        }
+        if (!tail) {
+            const char* a0 = tileA + kbytes;
+            const char* b0 = tileB + kbytes;
+            if constexpr (!CONV) {
+#pragma unroll
+                for (int q = 0; q < NAL; ++q) dma_piece(a0, offA[q], st + (NAL * wave + q) * 1024);
+            }
+#pragma unroll
+            for (int q = 0; q < NBL; ++q) dma_piece(b0, offB[q], st + (APIECES + NBL * wave + q) * 1024);
+        } else {                            // last step of a K that is not a multiple of 64: chunks past K read zeros
+            const uintptr_t kin[2] = {(uintptr_t)(-(long)(ks * G_BK + kofs[0] < p.K)),
+                                      (uintptr_t)(-(long)(ks * G_BK + kofs[1] < p.K))};
+            if constexpr (!CONV) {
+#pragma unroll
+                for (int q = 0; q < NAL; ++q) {
+                    unsigned o = offA[q];
+                    asm volatile("" : "+v"(o));      // keeps the 64-bit per-lane sum out of the loop's live registers
+                    const uintptr_t real = (uintptr_t)(tileA + kbytes + o);
+                    const uintptr_t a = zaddr + ((real - zaddr) & kin[(NAL * wave + q) & 1]);
+                    __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (NAL * wave + q) * 1024), 16, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NBL; ++q) {
+                unsigned o = offB[q];
+                asm volatile("" : "+v"(o));
+                const uintptr_t real = (uintptr_t)(tileB + kbytes + o);
+                const uintptr_t a = zaddr + ((real - zaddr) & kin[q & 1]);
+                __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (APIECES + NBL * wave + q) * 1024), 16, 0, 0);
             }
         }
     };
@@ -627,7 +659,8 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     if (g->K % chunk || g->ldb % chunk) return AVSR_EUNSUPPORTED;
     if (!aligned_to(g->A, 16) || !aligned_to(g->B, 16)) return AVSR_EUNSUPPORTED;
     if ((g->strideA * esz) % 16 || (g->strideB * esz) % 16) return AVSR_EUNSUPPORTED;
-    const bool conv = g->conv.enabled != 0;
+    bool conv = g->conv.enabled != 0;
+    int64_t lda = g->lda;
     if (conv) {
         const auto& c = g->conv;
         if (c.C % chunk || c.H <= 0 || c.W <= 0 || c.KH <= 0 || c.KW <= 0 || c.stride <= 0) return AVSR_EINVAL;
@@ -635,12 +668,17 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         if (c.OH != (c.H + 2 * c.pad_h - c.KH) / c.stride + 1) return AVSR_EINVAL;
         if (c.OW != (c.W + 2 * c.pad_w - c.KW) / c.stride + 1) return AVSR_EINVAL;
         if (g->M % ((int64_t)c.OH * c.OW)) return AVSR_EINVAL;
+        // a 1x1 / stride 1 / unpadded convolution over NHWC IS a dense product with lda = C: take the dense path
+        // (scalar-base operand addressing, no per-pixel cursors)
+        if (c.KH == 1 && c.KW == 1 && c.stride == 1 && c.pad_h == 0 && c.pad_w == 0) { conv = false; lda = c.C; }
     } else if (g->lda % chunk) return AVSR_EUNSUPPORTED;
+    // per-lane operand offsets inside a tile are 32-bit byte offsets
+    if (bf && (lda > (1 << 23) || g->ldb > (1 << 23))) return AVSR_EUNSUPPORTED;
 
     GemmP p;
     p.A = g->A; p.B = g->B; p.C = g->C;
     p.M = (int)g->M; p.N = (int)g->N; p.K = (int)g->K;
-    p.lda = g->lda; p.ldb = g->ldb; p.ldc = g->ldc;
+    p.lda = lda; p.ldb = g->ldb; p.ldc = g->ldc;
     p.sA = g->strideA; p.sB = g->strideB; p.sC = g->strideC;
     p.alpha = g->alpha; p.scale = g->scale; p.bias = g->bias; p.act = g->act;
     p.res = g->residual; p.ldr = g->ldr; p.res_period = (int)g->res_period; p.gate = g->gate; p.csum = g->col_sum; p.csq = g->col_sumsq;
