@@ -5,17 +5,30 @@
 // row once with one 256-thread block per row.
 #include "common.h"
 
-// lse[row] = log sum_v exp(x[row, v]); also sumx[row] = sum_v x[row, v].
-__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ x, long ld, int V, float* __restrict__ lse,
-                                                      float* __restrict__ sumx) {
+// lse[row] = log sum_v exp(x[row, v]); also sumx[row] = sum_v x[row, v].  One 1024-thread workgroup per row,
+// ONE pass with 16-byte loads: every thread keeps a running (max, sum of exp) pair that is rescaled when its
+// maximum moves, and the pairs are merged across the workgroup.  Rows must be 16-byte aligned (ld % 4 == 0).
+__global__ __launch_bounds__(1024) void row_lse_kernel(const float* __restrict__ x, long ld, int V, float* __restrict__ lse,
+                                                       float* __restrict__ sumx) {
     __shared__ float red[16];
     const float* xr = x + (long)blockIdx.x * ld;
-    float mx = -INFINITY;
-    for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, xr[v]);
-    mx = block_max(mx, red);
-    float s = 0.f, sx = 0.f;
-    for (int v = threadIdx.x; v < V; v += 256) { const float a = xr[v]; s += __expf(a - mx); sx += a; }
-    s = block_sum(s, red);
+    float m = -INFINITY, s = 0.f, sx = 0.f;
+    const int V4 = ((ld % 4 == 0) && ((uintptr_t)x % 16 == 0)) ? (V >> 2) : 0;
+    for (int i = threadIdx.x; i < V4; i += 1024) {
+        const f32x4 a = *(const f32x4*)(xr + 4 * i);
+        const float m4 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+        if (m4 > m) { s *= __expf(m - m4); m = m4; }
+        s += (__expf(a[0] - m) + __expf(a[1] - m)) + (__expf(a[2] - m) + __expf(a[3] - m));
+        sx += (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    for (int v = 4 * V4 + threadIdx.x; v < V; v += 1024) {
+        const float a = xr[v];
+        if (a > m) { s *= __expf(m - a); m = a; }
+        s += __expf(a - m);
+        sx += a;
+    }
+    const float mx = block_max(m, red);
+    s = block_sum(m == -INFINITY ? 0.f : s * __expf(m - mx), red);
     sx = block_sum(sx, red);
     if (threadIdx.x == 0) { lse[blockIdx.x] = mx + __logf(s); if (sumx) sumx[blockIdx.x] = sx; }
 }
@@ -53,56 +66,81 @@ __device__ __forceinline__ float lse2(float a, float b) {
 }
 __device__ __forceinline__ float lse3(float a, float b, float c) { return lse2(lse2(a, b), c); }
 
-// One block per batch item.  Extended label sequence l' = (blank, y1, blank,
-// ..., yL, blank), S = 2L+1 states.  alpha/beta are [B, T, Smax] in global
-// memory; time steps are separated by block barriers.  nll[b] = -log p(y|x);
-// with zero_infinity an infeasible alignment (nll = inf) is reported as inf
-// here and zeroed by the consumers.
+// Two workgroups per batch item (grid = 2B): workgroup b runs the forward (alpha) recursion and writes nll[b] =
+// -log p(y|x), workgroup B + b the backward (beta) one.  Extended label sequence l' = (blank, y1, blank, ..., yL,
+// blank), S = 2L+1 states.  The previous time step lives in LDS (two rows), and when the whole [Tb, S] table of
+// log-probabilities fits there too it is gathered up front in parallel, so a time step is LDS reads and one
+// barrier instead of dependent global gathers; every row is also written to the [B, T, Smax] global arrays for the
+// gradient kernel.  With zero_infinity an infeasible alignment (nll = inf) is reported as inf here and zeroed by
+// the consumers.
 __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __restrict__ x, long ld, const float* __restrict__ lse,
                                                              const int64_t* __restrict__ targets, long ldt,
                                                              const int64_t* __restrict__ in_len, const int64_t* __restrict__ tg_len,
                                                              float* __restrict__ alpha, float* __restrict__ beta,
-                                                             float* __restrict__ nll, int T, int Smax, int blank) {
-    const int b = blockIdx.x;
+                                                             float* __restrict__ nll, int B, int T, int Smax, int blank,
+                                                             int table_in_lds) {
+    extern __shared__ float ctc_lds[];                   // [2][Smax] state rows, then (optionally) the [Tb][S] table
+    const bool is_beta = (int)blockIdx.x >= B;
+    const int b = is_beta ? blockIdx.x - B : blockIdx.x;
     const int Tb = (int)min((long)in_len[b], (long)T);
     const int L = (int)tg_len[b];
     const int S = 2 * L + 1;
-    float* al = alpha + (long)b * T * Smax;
-    float* be = beta + (long)b * T * Smax;
+    float* out = (is_beta ? beta : alpha) + (long)b * T * Smax;
     const int64_t* tg = targets + (long)b * ldt;
     auto label = [&](int s) -> long { return (s & 1) ? tg[s >> 1] : (long)blank; };
     auto lp = [&](int t, long c) -> float { const long row = (long)b * T + t; return x[row * ld + c] - lse[row]; };
-    if (Tb <= 0 || S > Smax) { if (threadIdx.x == 0) nll[b] = INFINITY; return; }
-    for (int s = threadIdx.x; s < S; s += 256)
-        al[s] = (s == 0 || s == 1) ? lp(0, label(s)) : -INFINITY;
-    __syncthreads();
-    for (int t = 1; t < Tb; ++t) {
-        for (int s = threadIdx.x; s < S; s += 256) {
-            const long c = label(s);
-            const float a0 = al[(long)(t - 1) * Smax + s];
-            const float a1 = s >= 1 ? al[(long)(t - 1) * Smax + s - 1] : -INFINITY;
-            const float a2 = (s >= 2 && c != blank && label(s - 2) != c) ? al[(long)(t - 1) * Smax + s - 2] : -INFINITY;
-            al[(long)t * Smax + s] = lse3(a0, a1, a2) + lp(t, c);
-        }
+    if (Tb <= 0 || S > Smax) { if (threadIdx.x == 0 && !is_beta) nll[b] = INFINITY; return; }
+    float* st = ctc_lds;
+    float* tab = ctc_lds + 2 * Smax;
+    if (table_in_lds) {
+        for (int i = threadIdx.x; i < Tb * S; i += 256) { const int t = i / S, sidx = i - t * S; tab[i] = lp(t, label(sidx)); }
         __syncthreads();
     }
-    for (int s = threadIdx.x; s < S; s += 256)
-        be[(long)(Tb - 1) * Smax + s] = (s == S - 1 || s == S - 2) ? lp(Tb - 1, label(s)) : -INFINITY;
-    __syncthreads();
-    for (int t = Tb - 2; t >= 0; --t) {
-        for (int s = threadIdx.x; s < S; s += 256) {
-            const long c = label(s);
-            const float b0 = be[(long)(t + 1) * Smax + s];
-            const float b1 = s + 1 < S ? be[(long)(t + 1) * Smax + s + 1] : -INFINITY;
-            const float b2 = (s + 2 < S && c != blank && label(s + 2) != c) ? be[(long)(t + 1) * Smax + s + 2] : -INFINITY;
-            be[(long)t * Smax + s] = lse3(b0, b1, b2) + lp(t, c);
+    auto LP = [&](int t, int sidx, long c) -> float { return table_in_lds ? tab[t * S + sidx] : lp(t, c); };
+    if (!is_beta) {
+        for (int s0 = threadIdx.x; s0 < S; s0 += 256) {
+            const float v = (s0 == 0 || s0 == 1) ? LP(0, s0, label(s0)) : -INFINITY;
+            st[s0] = v; out[s0] = v;
         }
         __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const float e0 = al[(long)(Tb - 1) * Smax + S - 1];
-        const float e1 = S >= 2 ? al[(long)(Tb - 1) * Smax + S - 2] : -INFINITY;
-        nll[b] = -lse2(e0, e1);
+        for (int t = 1; t < Tb; ++t) {
+            const float* prev = st + ((t - 1) & 1) * Smax;
+            float* cur = st + (t & 1) * Smax;
+            for (int s0 = threadIdx.x; s0 < S; s0 += 256) {
+                const long c = label(s0);
+                const float a0 = prev[s0];
+                const float a1 = s0 >= 1 ? prev[s0 - 1] : -INFINITY;
+                const float a2 = (s0 >= 2 && c != blank && label(s0 - 2) != c) ? prev[s0 - 2] : -INFINITY;
+                const float v = lse3(a0, a1, a2) + LP(t, s0, c);
+                cur[s0] = v; out[(long)t * Smax + s0] = v;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float* last = st + ((Tb - 1) & 1) * Smax;
+            const float e0 = last[S - 1];
+            const float e1 = S >= 2 ? last[S - 2] : -INFINITY;
+            nll[b] = -lse2(e0, e1);
+        }
+    } else {
+        for (int s0 = threadIdx.x; s0 < S; s0 += 256) {
+            const float v = (s0 == S - 1 || s0 == S - 2) ? LP(Tb - 1, s0, label(s0)) : -INFINITY;
+            st[((Tb - 1) & 1) * Smax + s0] = v; out[(long)(Tb - 1) * Smax + s0] = v;
+        }
+        __syncthreads();
+        for (int t = Tb - 2; t >= 0; --t) {
+            const float* prev = st + ((t + 1) & 1) * Smax;
+            float* cur = st + (t & 1) * Smax;
+            for (int s0 = threadIdx.x; s0 < S; s0 += 256) {
+                const long c = label(s0);
+                const float b0 = prev[s0];
+                const float b1 = s0 + 1 < S ? prev[s0 + 1] : -INFINITY;
+                const float b2 = (s0 + 2 < S && c != blank && label(s0 + 2) != c) ? prev[s0 + 2] : -INFINITY;
+                const float v = lse3(b0, b1, b2) + LP(t, s0, c);
+                cur[s0] = v; out[(long)t * Smax + s0] = v;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -147,7 +185,20 @@ __global__ __launch_bounds__(256) void head_grad_dense_kernel(const float* __res
     TG* dr = dx + row * lddx;
     const float L = lse[row];
     const float gs = gctc + gce, c0 = gce * eps / (float)V, c1 = gce * (1.f - eps);
-    for (int v = threadIdx.x; v < V; v += 256) {
+    const bool vec = (ld % 4 == 0) && (lddx % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dx % 16 == 0);
+    const int V4 = vec ? (V >> 2) : 0;
+    for (int i = threadIdx.x; i < V4; i += 256) {               // 16-byte loads, 8- or 16-byte stores
+        const f32x4 a = *(const f32x4*)(xr + 4 * i);
+        float g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            g[e] = gs * __expf(a[e] - L) - c0;
+            if (4 * i + e == tg) g[e] -= c1;
+        }
+        if constexpr (sizeof(TG) == 4) *(f32x4*)(dr + 4 * i) = (f32x4){g[0], g[1], g[2], g[3]};
+        else *(bf16x4*)(dr + 4 * i) = (bf16x4){(bf16_t)g[0], (bf16_t)g[1], (bf16_t)g[2], (bf16_t)g[3]};
+    }
+    for (int v = 4 * V4 + threadIdx.x; v < V; v += 256) {
         float g = gs * __expf(xr[v] - L) - c0;
         if (v == tg) g -= c1;
         dr[v] = from_f32<TG>(g);
@@ -232,11 +283,14 @@ extern "C" int avsr_head_loss_fwd(avsr_stream_t stream, const float* logits, int
     float* lse = ws; float* sumx = lse + rows; float* nll = sumx + rows; float* ce = nll + B;
     float* alpha = ce + 2; float* beta = alpha + rows * Smax;
     const int t_ce = (int)(T < max_target_len ? T : max_target_len);
-    hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, (long)ld, (int)V, lse, sumx);
+    hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)rows), dim3(1024), 0, s, logits, (long)ld, (int)V, lse, sumx);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, logits, (long)ld, (int)V, lse, sumx, targets, (long)ldt,
                        (int)B, (int)T, t_ce, label_smoothing, (int)ignore_index, ce);
-    hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3((unsigned)B), dim3(256), 0, s, logits, (long)ld, lse, targets, (long)ldt,
-                       input_lengths, target_lengths, alpha, beta, nll, (int)T, (int)Smax, (int)blank);
+    const size_t tab_bytes = (size_t)T * Smax * sizeof(float), st_bytes = 2 * (size_t)Smax * sizeof(float);
+    const int in_lds = tab_bytes + st_bytes <= 60 * 1024;
+    hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3((unsigned)(2 * B)), dim3(256), st_bytes + (in_lds ? tab_bytes : 0), s, logits,
+                       (long)ld, lse, targets, (long)ldt, input_lengths, target_lengths, alpha, beta, nll, (int)B, (int)T,
+                       (int)Smax, (int)blank, in_lds);
     hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(64), 0, s, nll, target_lengths, (int)B, out3);
     // out3 = {ctc, ce, n_ce_targets}: copy ce[0], ce[1] behind the ctc value
     if (hipMemcpyAsync(out3 + 1, ce, 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_EHIP;

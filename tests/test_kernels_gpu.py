@@ -366,15 +366,17 @@ def test_stem_pool_bn(dev, odt):
     assert rel_err(pooled, refp) < tol(odt)
 
 
-def test_head_loss(dev):
-    g = torch.Generator().manual_seed(9)
-    B, T, V, L = 3, 20, 501, 6
-    ld = 504
+@pytest.mark.parametrize("T,V,L,ld", [(20, 501, 6, 504), (300, 203, 40, 203), (75, 1030, 32, 1032)])
+def test_head_loss(dev, T, V, L, ld):
+    """Log-softmax + label-smoothed CE + CTC and their fused gradient against torch.  (300, 40) is past what the
+    CTC kernel keeps in LDS (global-gather path), ld = 203 exercises the unaligned-row (scalar) paths."""
+    g = torch.Generator().manual_seed(9 + T)
+    B = 3
     logits = torch.randn(B, T, V, generator=g) * 2
     targets = torch.randint(1, V, (B, L), generator=g)
     targets[1, 2] = targets[1, 1]                     # repeated label
-    tl = torch.tensor([6, 4, 5])
-    il = torch.tensor([20, 15, 4])                    # last one infeasible (5 labels in 4 frames) -> zero_infinity
+    tl = torch.tensor([L, L - 2, L - 1])
+    il = torch.tensor([T, T - 5, L - 2])              # last one infeasible (L-1 labels in L-2 frames) -> zero_infinity
     lr = logits.clone().requires_grad_(True)
     lp = F.log_softmax(lr, -1).transpose(0, 1)
     ctc = F.ctc_loss(lp, targets, il, tl, blank=0, reduction="mean", zero_infinity=True)
