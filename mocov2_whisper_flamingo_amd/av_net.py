@@ -116,6 +116,10 @@ class AVNet(nn.Module):
             vis.record_stream(main)
         else:
             vis = self.visual_model(videoBatch, videoLen)                   # [B,Tv,2048]
+        ready = getattr(self, "_weights_ready", None)     # compute-dtype weight copies rebuilt on another stream
+        if ready is not None:
+            main.wait_event(ready)
+            self._weights_ready = None
         B, Ta, D = enc.shape
         Tv = vis.shape[1]
         min_len = min(Ta, Tv)

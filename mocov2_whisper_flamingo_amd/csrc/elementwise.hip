@@ -271,7 +271,7 @@ extern "C" int avsr_gated_residual_bwd(avsr_stream_t stream, int dtype, const vo
                                        void* dy, float* dgate, int64_t n, float p_drop, uint64_t seed) {
     if (!dout || !y || !gate || !dy || !dgate || n <= 0 || p_drop < 0.f || p_drop >= 1.f) return AVSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(grid_for(n, 256, 1024)), block(256);
+    dim3 grid(grid_for(n, 256, 64)), block(256);      // few workgroups: each ends in ONE atomic on the gate gradient
     if (dtype == AVSR_F32) hipLaunchKernelGGL(gated_residual_bwd_kernel<float>, grid, block, 0, s, (const float*)dout, (const float*)y, gate, (float*)dy, dgate, (long)n, p_drop, seed);
     else if (dtype == AVSR_BF16) hipLaunchKernelGGL(gated_residual_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dout, (const bf16_t*)y, gate, (bf16_t*)dy, dgate, (long)n, p_drop, seed);
     else return AVSR_EINVAL;

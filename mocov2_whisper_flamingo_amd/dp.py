@@ -171,6 +171,13 @@ class FlatTrainer:
         cache = getattr(self.model, "_cache", None)
         if cache is not None:
             cache.bump()
+            if self.grad_stream is not None:
+                # rebuild the bf16 W / W^T copies now, beside the next step's frozen encoders; the next zero_grad /
+                # backward / step joins this stream, and the forward tail waits for it through `weights_ready`
+                cache.refresh(self.grad_stream)
+                self.weights_ready = torch.cuda.Event()
+                self.weights_ready.record(self.grad_stream)
+                self.model._weights_ready = self.weights_ready
         return scr[2:3]
 
     def grad_norm(self):

@@ -26,12 +26,30 @@ class WeightCache:
         """Invalidate every copy (the weights were updated in place outside autograd)."""
         self.epoch += 1
 
+    def refresh(self, stream=None):
+        """Rebuild every cached copy now, on ``stream`` (off the critical path: right after the optimizer step the
+        next step's frozen encoders run for milliseconds before the first trainable weight is read).  The caller
+        makes the consuming stream wait for ``stream``."""
+        params = [ent[3] for ent in self._store.values()]
+        if stream is None:
+            for p in params:
+                self.get(p)
+            return
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            for p in params:
+                self.get(p)
+
     def get(self, p):
         key = id(p)
         hit = self._store.get(key)
         ver = (p._version, p.data_ptr(), self.epoch)
         if hit is not None and hit[0] == ver:
             return hit[1], hit[2]
+        if hit is not None:                       # the old copies may still be read by kernels in flight on another stream
+            for t in (hit[1], hit[2]):
+                if t.is_cuda:
+                    t.record_stream(torch.cuda.current_stream())
         with torch.no_grad():
             w = p.detach()
             # big vocabulary heads: pad N so the dX product can split its K (= N) 16 ways in 64-element steps
@@ -40,7 +58,7 @@ class WeightCache:
                 wc, wct = w, ops.transpose2d(w, dtype=self.dtype, pad_to=pad)
             else:                      # compute-dtype copy and its transpose in one pass over the fp32 master
                 wct, wc = ops.transpose2d(w, dtype=self.dtype, pad_to=pad, with_copy=True)
-        self._store[key] = (ver, wc, wct)
+        self._store[key] = (ver, wc, wct, p)
         return wc, wct
 
     def clear(self):
