@@ -105,6 +105,7 @@ class FlatTrainer:
     def _arm(self):
         for b in self.buckets:
             b["left"] = len(b["params"])
+        self._seen = set()
 
     def _reduce_bucket(self, b):
         lo, hi = b["range"]
@@ -120,6 +121,11 @@ class FlatTrainer:
         self._works.append(w)
 
     def _on_grad_ready(self, p):
+        # a parameter can be announced twice in one step (by the kernels' own notification and by autograd's
+        # post-accumulate hook, which also runs for a gradient that was handed back as None): count it once
+        if id(p) in self._seen:
+            return
+        self._seen.add(id(p))
         b = self._bucket_of[id(p)]
         b["left"] -= 1
         if b["left"] == 0:

@@ -340,3 +340,65 @@ def test_flat_trainer_direct_gradients_match_autograd(dev, dtype):
         if rep == 0:                                                   # a second backward accumulates on both sides
             run(ma)
             run(mb)
+
+
+def _dp_gpu_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mocov2_whisper_flamingo_amd.dp import FlatTrainer
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        m, sd = _micro_avnet(torch.float32, dev, p_drop=0.0)
+        m.eval()                                             # running-statistics BN: the full batch and its halves agree
+        tr = FlatTrainer(m, bucket_mb=0.25, overlap=bool(int(os.environ.get("AVSR_TEST_OVERLAP", "1"))))    # small buckets: several all-reduces launched from the hooks
+        full = synthetic_batch(B=2 * world, Tv=6, H=32, W=32, L=4, vocab=503, seed=3)
+        mine = to_device({k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}, dev)
+        tr.zero_grad()
+        loss, *_ = m.training_step(mine)
+        loss.backward()
+        tr.reduce_gradients()
+        torch.cuda.synchronize()
+        if rank == 0:
+            _, _, _, _, ref, _ = oracle.training_step(sd, full, 2, 2, training=False, masked_row="zero")
+            params = dict(m.named_parameters())
+            errs = {k: ((params[k].grad.cpu() - ref[k]).abs().max() / ref[k].abs().max().clamp_min(1e-6)).item()
+                    for k in ref}
+            worst = max(errs.values())
+            if worst >= 1e-3:
+                print("per-parameter relative errors:", {k: round(v, 4) for k, v in errs.items() if v >= 1e-3}, flush=True)
+            q.put(("ok", worst, len(tr.buckets)))
+        dist.barrier()
+    except Exception as e:                                    # surface the failure instead of a timeout
+        if rank == 0:
+            q.put(("error", repr(e), 0))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_hooks_and_direct_gradients_two_ranks_one_gpu(dev):
+    """Two ranks (gloo, both on this GPU) run the HIP training step on half a batch each with FlatTrainer's
+    bucket hooks, gradient stream and communication stream active; the averaged gradients must equal the
+    oracle's full-batch gradients.  This is the N > 1 control path the multi-GPU benchmark uses, minus RCCL."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        status, worst, nb = q.get(timeout=150)
+        for p in procs:
+            p.join(60)
+    finally:
+        for p in procs:                                       # a stuck rank must not outlive the test
+            if p.is_alive():
+                p.kill()
+    assert status == "ok", worst
+    assert all(p.exitcode == 0 for p in procs)
+    assert nb > 1 and worst < 1e-3
