@@ -119,12 +119,16 @@ int avsr_layernorm_bwd(avsr_stream_t stream, int x_dtype, int g_dtype, const voi
  * counter-based generator: element (row = (b*H+h)*Tq + q, key) uses output
  * (key & 3) of counter row*ceil(Tk/4) + key/4 under `seed`; forward and
  * backward, MFMA and fp32 kernels all draw the same mask.
+ * causal = 1 (forward only; the Whisper decoder self-attention,
+ * hf modeling_whisper.py:416-505, is_causal): query i sees keys
+ * <= i + (Tk - Tq), i.e. the queries are the last Tq positions of the
+ * Tk-long key sequence; needs Tk >= Tq; combines with key_mask.
  * ---------------------------------------------------------------------- */
 int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
                   int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
                   float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
-                  float p_drop, uint64_t seed);
-/* d_ws: fp32 [B,H,Tq] scratch (row sums of dO*O). */
+                  float p_drop, uint64_t seed, int causal);
+/* d_ws: fp32 [B,H,Tq] scratch (row sums of dO*O).  Not for a causal forward. */
 int avsr_attn_bwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
                   int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo, const void* dO, int64_t lddo,
                   void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv,
@@ -250,6 +254,13 @@ int avsr_sum_parts(avsr_stream_t stream, int out_dtype, const float* parts, int6
                    const float* bias, int64_t ncol, void* out, int64_t n);
 /* out = a + b + c (c may be NULL)  (models/av_net.py:106) */
 int avsr_add3(avsr_stream_t stream, int dtype, const void* a, const void* b, const void* c, void* out, int64_t n);
+/* Whisper decoder input (hf modeling_whisper.py:649-797: embed_tokens(ids) * embed_scale +
+ * embed_positions.weight[past : past + T]): out[row, :] = table[ids[row], :] * scale + pos[past + row % T, :],
+ * fp32 [rows, D] with rows = batch * T.  table: [V, D] fp32 or bf16; pos: fp32 [n_pos, D]; past + T <= n_pos.
+ * An id outside [0, V) contributes a zero embedding and sets *bad_id_flag (device int, may be NULL). */
+int avsr_embed_tokens(avsr_stream_t stream, int table_dtype, const int64_t* ids, const void* table, const float* pos,
+                      float* out, int64_t rows, int64_t T, int64_t past, int64_t D, int64_t V, int64_t n_pos,
+                      float scale, int* bad_id_flag);
 
 /* ------------------------------------------------------------------------
  * Optimizer step of train.py:218-225,321: global-norm clipping and AdamW over

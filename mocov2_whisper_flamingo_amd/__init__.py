@@ -9,6 +9,7 @@ from .gate_cross_attention import GatedCrossAttentionBlock, GatedCrossModalFusio
 from .moco_visual_frontend import MoCoVisualFrontend
 from .utils import Decoder, PositionalEncoding
 from .whisper_encoder import WhisperConfig, WhisperEncoder, WhisperModel
+from .whisper_decoder import WhisperDecoder
 
 __all__ = ["AVNet", "GatedCrossAttentionBlock", "GatedCrossModalFusion", "LayerNorm", "LogMelFrontend", "MoCoVisualFrontend",
-           "Decoder", "PositionalEncoding", "WhisperConfig", "WhisperEncoder", "WhisperModel", "ops"]
+           "Decoder", "PositionalEncoding", "WhisperConfig", "WhisperDecoder", "WhisperEncoder", "WhisperModel", "ops"]

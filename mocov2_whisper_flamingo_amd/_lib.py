@@ -39,7 +39,7 @@ SIGNATURES = {
     "avsr_layernorm_fwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _f32]),
     "avsr_layernorm_bwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64]),
     "avsr_attn_fwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
-                             _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64]),
+                             _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64, _i32]),
     "avsr_attn_bwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
                              _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64]),
     "avsr_logmel_dft_table_floats": (_i64, []),
@@ -72,6 +72,7 @@ SIGNATURES = {
     "avsr_gated_residual_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _u64]),
     "avsr_sum_parts": (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _i64, _vp, _i64]),
     "avsr_add3": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64]),
+    "avsr_embed_tokens": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp]),
     "avsr_sumsq_accumulate": (_i32, [_vp, _vp, _i64, _vp]),
     "avsr_clip_scale": (_i32, [_vp, _vp, _f32, _vp, _vp]),
     "avsr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _vp]),

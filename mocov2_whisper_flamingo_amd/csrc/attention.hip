@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
                                                             long ldk, const bf16_t* __restrict__ V, long ldv,
                                                             bf16_t* __restrict__ O, long ldo, const uint8_t* __restrict__ mask,
                                                             float* __restrict__ lse, int Tq, int Tk, int H, float scale,
-                                                            float pdrop, uint64_t seed, int B) {
+                                                            float pdrop, uint64_t seed, int B, int causal) {
     __shared__ __attribute__((aligned(16))) bf16_t Kbuf[2][64 * 64];      // double-buffered: one barrier per key tile
     __shared__ __attribute__((aligned(16))) bf16_t Vbuf[2][64 * 64];
     // 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs (id % 8), each with its own L2.  All
@@ -113,13 +113,17 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
             *(bf16x8*)&Vbuf[buf][v_off(lr + 32 * i, lc)] = vreg[i];
         }
     };
+    // causal: query i sees keys <= i + (Tk - Tq) (the last Tq positions of a Tk-long sequence), so this
+    // workgroup's key loop ends at the diagonal of its last query row
+    const int coff = Tk - Tq;
+    const int kend = causal ? min(Tk, qt * 128 + 128 + coff) : Tk;
     prefetch(0);
     stage(0);
     __syncthreads();
-    for (int kv0 = 0, cur = 0; kv0 < Tk; kv0 += 64, cur ^= 1) {
+    for (int kv0 = 0, cur = 0; kv0 < kend; kv0 += 64, cur ^= 1) {
         const bf16_t* Ks = Kbuf[cur];
         const bf16_t* Vs = Vbuf[cur];
-        const bool more = kv0 + 64 < Tk;
+        const bool more = kv0 + 64 < kend;
         if (more) prefetch(kv0 + 64);                         // lands in registers while this tile is computed
 
         f32x16 sacc[2];
@@ -143,6 +147,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
                     for (int i = 0; i < 16; ++i)
                         if ((dead >> (32 * st + (i & 3) + 8 * (i >> 2) + 4 * hf)) & 1) sacc[st][i] = -INFINITY;
             }
+        }
+        if (causal && kv0 + 63 > qt * 128 + coff) {          // block-uniform: only tiles that touch the diagonal
+            const int last = q + coff - kv0;                  // last visible key of this lane's row, tile-relative
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (32 * st + (i & 3) + 8 * (i >> 2) + 4 * hf > last) sacc[st][i] = -INFINITY;
         }
         float mx = sacc[0][0];
 #pragma unroll
@@ -457,26 +469,30 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_valu_kernel(const T* __restrict__ Q, long ldq, const T* __restrict__ K, long ldk,
                                                             const T* __restrict__ V, long ldv, T* __restrict__ O, long ldo,
                                                             const uint8_t* __restrict__ mask, float* __restrict__ lse,
-                                                            int Tq, int Tk, int H, float scale, float pdrop, uint64_t seed) {
+                                                            int Tq, int Tk, int H, float scale, float pdrop, uint64_t seed,
+                                                            int causal) {
     __shared__ float Ks[64 * KLD], Vs[64 * KLD], Qs[32 * KLD];
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     stage_rows_f32<T>(Qs, Q + (long)b * Tq * ldq + h * HD, ldq, q0, 32, Tq);
+    const int coff = Tk - Tq;                                 // causal: query i sees keys <= i + coff
+    const int kend = causal ? min(Tk, q0 + 32 + coff) : Tk;
     float m[8], l[8], o[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { m[i] = -INFINITY; l[i] = 0.f; o[i] = 0.f; }
     const uint8_t* mb = mask ? mask + (long)b * Tk : nullptr;
     const float keep_scale = pdrop > 0.f ? 1.0f / (1.0f - pdrop) : 1.0f;
-    for (int kv0 = 0; kv0 < Tk; kv0 += 64) {
+    for (int kv0 = 0; kv0 < kend; kv0 += 64) {
         __syncthreads();
         stage_rows_f32<T>(Ks, K + (long)b * Tk * ldk + h * HD, ldk, kv0, 64, Tk);
         stage_rows_f32<T>(Vs, V + (long)b * Tk * ldv + h * HD, ldv, kv0, 64, Tk);
         __syncthreads();
         const int key = kv0 + lane;
-        const bool dead = key >= Tk || (mb && mb[key < Tk ? key : 0]);
+        const bool masked = key >= Tk || (mb && mb[key < Tk ? key : 0]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int qr = wave * 8 + i, qg = q0 + qr;
+            const bool dead = masked || (causal && key > qg + coff);
             float s = 0.f;
 #pragma unroll 16
             for (int d = 0; d < 64; ++d) s = fmaf(Qs[qr * KLD + d], Ks[lane * KLD + d], s);
@@ -646,8 +662,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_valu_kernel(const T* __restr
 extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
                              int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
                              float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
-                             float p_drop, uint64_t seed) {
+                             float p_drop, uint64_t seed, int causal) {
     if (!Q || !K || !V || !O || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return AVSR_EINVAL;
+    if (causal && Tk < Tq) return AVSR_EINVAL;
     if (head_dim != HD) return AVSR_EUNSUPPORTED;
     if (B > 65535 || H > 65535) return AVSR_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -661,22 +678,22 @@ extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, cons
         if (p_drop > 0.f)
             hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                                (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
-                               (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, (int)B);
+                               (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, (int)B, causal);
         else
             hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                                (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
-                               (int)Tq, (int)Tk, (int)H, scale, 0.f, seed, (int)B);
+                               (int)Tq, (int)Tk, (int)H, scale, 0.f, seed, (int)B, causal);
         return avsr_launch_status();
     }
     dim3 grid((unsigned)((Tq + 31) / 32), (unsigned)H, (unsigned)B);
     if (dtype == AVSR_F32)
         hipLaunchKernelGGL(attn_fwd_valu_kernel<float>, grid, dim3(256), 0, s, (const float*)Q, (long)ldq, (const float*)K,
                            (long)ldk, (const float*)V, (long)ldv, (float*)O, (long)ldo, key_mask, lse, (int)Tq, (int)Tk,
-                           (int)H, scale, p_drop, seed);
+                           (int)H, scale, p_drop, seed, causal);
     else if (dtype == AVSR_BF16)
         hipLaunchKernelGGL(attn_fwd_valu_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                            (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
-                           (int)Tq, (int)Tk, (int)H, scale, p_drop, seed);
+                           (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, causal);
     else return AVSR_EINVAL;
     return avsr_launch_status();
 }

@@ -192,6 +192,32 @@ static inline unsigned grid_for(long n, int per_block, long cap) {
     return (unsigned)nb;
 }
 
+// out[row, :] = table[ids[row], :] * scale + pos[past + row % T, :]: token + learned position embeddings of
+// the Whisper decoder, written to the fp32 residual stream.  An id outside [0, V) writes the position row
+// alone and raises the error flag (the host reports it), never reads outside the table.
+template <typename TW>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const long* __restrict__ ids, const TW* __restrict__ table,
+                                                           const float* __restrict__ pos, float* __restrict__ out, long rows,
+                                                           int T, int past, int D, long V, float scale, int* __restrict__ bad) {
+    const int d4 = D >> 2;
+    const long n = rows * d4, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long row = i / d4;
+        const int c = (int)(i - row * d4) * 4;
+        const long id = ids[row];
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        if (id >= 0 && id < V) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = to_f32<TW>(table[id * D + c + k]);
+        } else if (c == 0 && bad) atomicOr(bad, 1);
+        const f32x4 pp = *(const f32x4*)(pos + (long)(past + (int)(row % T)) * D + c);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = e[k] * scale + pp[k];
+        *(f32x4*)(out + row * D + c) = o;
+    }
+}
+
 extern "C" int avsr_cast(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y, int64_t n, float scale) {
     if (!x || !y || n <= 0) return AVSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -274,6 +300,24 @@ extern "C" int avsr_gated_residual_bwd(avsr_stream_t stream, int dtype, const vo
     dim3 grid(grid_for(n, 256, 64)), block(256);      // few workgroups: each ends in ONE atomic on the gate gradient
     if (dtype == AVSR_F32) hipLaunchKernelGGL(gated_residual_bwd_kernel<float>, grid, block, 0, s, (const float*)dout, (const float*)y, gate, (float*)dy, dgate, (long)n, p_drop, seed);
     else if (dtype == AVSR_BF16) hipLaunchKernelGGL(gated_residual_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dout, (const bf16_t*)y, gate, (bf16_t*)dy, dgate, (long)n, p_drop, seed);
+    else return AVSR_EINVAL;
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_embed_tokens(avsr_stream_t stream, int table_dtype, const int64_t* ids, const void* table, const float* pos,
+                                 float* out, int64_t rows, int64_t T, int64_t past, int64_t D, int64_t V, int64_t n_pos,
+                                 float scale, int* bad_id_flag) {
+    if (!ids || !table || !pos || !out || rows <= 0 || T <= 0 || past < 0 || D <= 0 || V <= 0) return AVSR_EINVAL;
+    if (past + T > n_pos) return AVSR_EINVAL;                  // more positions than the learned table holds
+    if (D % 4 || ((uintptr_t)table | (uintptr_t)pos | (uintptr_t)out) % 16) return AVSR_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(grid_for(rows * (D / 4), 256, 4096)), block(256);
+    if (table_dtype == AVSR_F32)
+        hipLaunchKernelGGL(embed_tokens_kernel<float>, grid, block, 0, s, (const long*)ids, (const float*)table, pos, out,
+                           (long)rows, (int)T, (int)past, (int)D, (long)V, scale, bad_id_flag);
+    else if (table_dtype == AVSR_BF16)
+        hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, grid, block, 0, s, (const long*)ids, (const bf16_t*)table, pos, out,
+                           (long)rows, (int)T, (int)past, (int)D, (long)V, scale, bad_id_flag);
     else return AVSR_EINVAL;
     return avsr_launch_status();
 }

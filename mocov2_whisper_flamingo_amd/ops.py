@@ -191,8 +191,9 @@ def _bthd(t, H):
     return t.stride(1)
 
 
-def attn_fwd(q, k, v, H, *, key_mask=None, scale=1.0, use_mfma=False, save_lse=False, p_drop=0.0, seed=0):
-    """q: [B,Tq,H*64] view, k/v: [B,Tk,H*64] views (may be column slices of a fused QKV buffer)."""
+def attn_fwd(q, k, v, H, *, key_mask=None, scale=1.0, use_mfma=False, save_lse=False, p_drop=0.0, seed=0, causal=False):
+    """q: [B,Tq,H*64] view, k/v: [B,Tk,H*64] views (may be column slices of a fused QKV buffer).
+    ``causal``: query i sees keys <= i + (Tk - Tq); forward only (attn_bwd has no causal form)."""
     lib = _lib.load()
     _need_cuda(q, k, v, key_mask)
     B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
@@ -202,7 +203,7 @@ def attn_fwd(q, k, v, H, *, key_mask=None, scale=1.0, use_mfma=False, save_lse=F
         raise ValueError("key_mask must be contiguous uint8 [B,Tk]")
     check(lib.avsr_attn_fwd(_stream(), _dt(q), int(use_mfma), q.data_ptr(), _bthd(q, H), k.data_ptr(), _bthd(k, H),
                             v.data_ptr(), _bthd(v, H), o.data_ptr(), H * 64, _p(key_mask), _p(lse), B, H, Tq, Tk, 64,
-                            scale, p_drop, seed), "avsr_attn_fwd")
+                            scale, p_drop, seed, int(causal)), "avsr_attn_fwd")
     return (o, lse) if save_lse else o
 
 
@@ -459,6 +460,25 @@ def add3(a, b, c=None):
     lib = _lib.load()
     out = torch.empty_like(a)
     check(lib.avsr_add3(_stream(), _dt(a), a.data_ptr(), b.data_ptr(), _p(c), out.data_ptr(), a.numel()), "avsr_add3")
+    return out
+
+
+def embed_tokens(ids, table, pos, past=0, scale=1.0):
+    """ids [B,T] int64 -> fp32 [B*T, D]: table[ids] * scale + pos[past:past+T] (Whisper decoder input).
+    Raises IndexError on an id outside the table, as nn.Embedding does."""
+    lib = _lib.load()
+    _need_cuda(ids, table, pos)
+    if ids.dtype != torch.int64 or ids.dim() != 2:
+        raise ValueError("ids must be int64 [B,T]")
+    B, T = ids.shape
+    V, D = table.shape
+    ids = ids.contiguous()
+    out = torch.empty((B * T, D), dtype=torch.float32, device=ids.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=ids.device)
+    check(lib.avsr_embed_tokens(_stream(), _dt(table), ids.data_ptr(), table.data_ptr(), pos.data_ptr(), out.data_ptr(),
+                                B * T, T, past, D, V, pos.shape[0], scale, bad.data_ptr()), "avsr_embed_tokens")
+    if int(bad.item()):
+        raise IndexError("token id out of range for the embedding table")
     return out
 
 

@@ -2,7 +2,7 @@
 the reference's checkpoint key names (``whisper_model.encoder.*`` /
 ``whisper_model.decoder.*``; the reference builds them with
 ``WhisperModel.from_pretrained`` at models/av_net.py:22 and only ever runs the
-encoder, models/av_net.py:78-81).
+encoder, models/av_net.py:78-81; the decoder lives in whisper_decoder.py).
 
 The encoder is frozen in the reference (models/av_net.py:25-26), so there is
 no backward here: ``WhisperEncoder.forward`` runs under ``no_grad``.
@@ -74,30 +74,6 @@ class _EncoderLayer(nn.Module):
         self.fc1 = nn.Linear(d, 4 * d)
         self.fc2 = nn.Linear(4 * d, d)
         self.final_layer_norm = nn.LayerNorm(d)
-
-
-class _DecoderLayer(nn.Module):
-    """Parameter container only: the reference never executes the decoder."""
-
-    def __init__(self, d):
-        super().__init__()
-        self.self_attn = _Attention(d)
-        self.self_attn_layer_norm = nn.LayerNorm(d)
-        self.encoder_attn = _Attention(d)
-        self.encoder_attn_layer_norm = nn.LayerNorm(d)
-        self.fc1 = nn.Linear(d, 4 * d)
-        self.fc2 = nn.Linear(4 * d, d)
-        self.final_layer_norm = nn.LayerNorm(d)
-
-
-class WhisperDecoderParams(nn.Module):
-    def __init__(self, cfg):
-        super().__init__()
-        d = cfg.d_model
-        self.embed_tokens = nn.Embedding(cfg.vocab_size, d)
-        self.embed_positions = nn.Embedding(cfg.max_target_positions, d)
-        self.layers = nn.ModuleList([_DecoderLayer(d) for _ in range(cfg.decoder_layers)])
-        self.layer_norm = nn.LayerNorm(d)
 
 
 class WhisperEncoder(nn.Module):
@@ -199,11 +175,12 @@ class WhisperEncoder(nn.Module):
 
 class WhisperModel(nn.Module):
     """Container with the HF attribute names the reference touches:
-    ``.encoder``, ``.decoder`` (parameters only) and ``.config.d_model``."""
+    ``.encoder``, ``.decoder`` (constructed by the reference, never called by it) and ``.config.d_model``."""
 
     def __init__(self, config):
         super().__init__()
         self.config = config
         self.encoder = WhisperEncoder(config)
         if config.with_decoder:
-            self.decoder = WhisperDecoderParams(config)
+            from .whisper_decoder import WhisperDecoder
+            self.decoder = WhisperDecoder(config)

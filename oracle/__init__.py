@@ -17,9 +17,10 @@ Pinning status
 * fusion / LayerNorm / PositionalEncoding / Decoder: pinned against the
   reference's own classes (``models/gate_cross_attention.py``,
   ``models/utils.py``) through ``tests/golden/*.npz``.
-* Whisper encoder and Whisper log-mel: pinned against the ``transformers``
-  implementation the reference calls (``models/av_net.py:22,78``), live in
-  ``tests/test_oracle_vs_transformers.py`` and through goldens.
+* Whisper encoder, Whisper decoder and Whisper log-mel: pinned against the
+  ``transformers`` implementation the reference constructs / calls
+  (``models/av_net.py:22,78``), live in ``tests/test_oracle_cpu.py`` and
+  through goldens.
 * ResNet-50 trunk, 3D stem, torchaudio MelSpectrogram variant: PARITY UNPINNED -
   ``torchvision`` / ``torchaudio`` are not installed, and the reference holds no
   fixtures for them; the restatement follows the published architecture and is
@@ -27,7 +28,7 @@ Pinning status
 """
 from .ref_fusion import (layer_norm_fp32, positional_encoding, gated_block,
                          fusion_forward, mha_forward)
-from .ref_whisper import whisper_encoder
+from .ref_whisper import whisper_encoder, whisper_decoder
 from .ref_visual import visual_frontend
 from .ref_avnet import avnet_forward, ctc_ce_loss, training_step, make_padding_mask
 from .ref_logmel import whisper_logmel, torchaudio_melspec_norm

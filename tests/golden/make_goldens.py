@@ -11,6 +11,9 @@ What is pinned, and by what:
                   pytorch_lightning, which is not installed).
   whisper.npz   - transformers' WhisperEncoder (the class models/av_net.py:78 calls), eager attention, random
                   init from the same seeded recipe: a micro config in full, Whisper-tiny as row samples + sums.
+  whisper_decoder.npz - transformers' WhisperDecoder (the ``whisper_model.decoder`` the reference constructs at
+                  models/av_net.py:22 and never calls), eager attention, same seeded recipe: micro config in full,
+                  with and without a padded decoder attention_mask.
   logmel.npz    - transformers' WhisperFeatureExtractor built from the reference's TW_tokenizer/
                   preprocessor_config.json, on a seeded 10 s waveform.
 Inputs are regenerated from seeds on both sides (tests/helpers.py); only outputs are stored.
@@ -98,6 +101,25 @@ def whisper_golden():
     np.savez_compressed(os.path.join(HERE, "whisper.npz"), **out)
 
 
+def whisper_decoder_golden():
+    from transformers import WhisperConfig, WhisperModel
+    D, Ly, H, B, T, Te, V = 128, 2, 2, 2, 12, 40, 503
+    cfg = WhisperConfig(d_model=D, encoder_layers=1, encoder_attention_heads=H, encoder_ffn_dim=4 * D,
+                        decoder_layers=Ly, decoder_attention_heads=H, decoder_ffn_dim=4 * D, num_mel_bins=80,
+                        vocab_size=V, max_target_positions=64, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                        decoder_start_token_id=1, attn_implementation="eager")
+    dec = load_seeded(WhisperModel(cfg).decoder, 17).eval()
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(3, V, (B, T), generator=g)
+    enc = torch.randn(B, Te, D, generator=g)
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, 9:] = 0
+    with torch.no_grad():
+        y = dec(input_ids=ids, encoder_hidden_states=enc, use_cache=False)[0]
+        ym = dec(input_ids=ids, attention_mask=am, encoder_hidden_states=enc, use_cache=False)[0]
+    np.savez_compressed(os.path.join(HERE, "whisper_decoder.npz"), y=y.numpy(), y_masked=ym.numpy())
+
+
 def logmel_golden():
     from transformers import WhisperFeatureExtractor
     fe = WhisperFeatureExtractor.from_pretrained("/root/reference/TW_tokenizer")
@@ -113,6 +135,7 @@ if __name__ == "__main__":
     fusion_golden()
     head_pe_golden()
     whisper_golden()
+    whisper_decoder_golden()
     logmel_golden()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -42,6 +42,42 @@ def test_whisper_encoder(dev, dtype, name):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_whisper_decoder(dev, dtype):
+    """Decoder blocks (causal self-attention, cross-attention to the encoder output, MLP) against the oracle,
+    which is pinned to transformers' WhisperDecoder: full sequence, padded attention_mask, no encoder, and the
+    maximum 448-token sequence against a 1500-frame encoder output."""
+    cfg = WhisperConfig(d_model=128, decoder_layers=2, decoder_attention_heads=2, vocab_size=503, max_target_positions=448)
+    m = WhisperModel(cfg)
+    sd = seed_module(m, 17)
+    m.to(dev)
+    g = torch.Generator().manual_seed(9)
+    for B, T, Te in ((2, 12, 40), (2, 448, 1500)):
+        ids = torch.randint(3, 503, (B, T), generator=g)
+        enc = torch.randn(B, Te, 128, generator=g)
+        am = torch.ones(B, T, dtype=torch.long)
+        am[1, T - T // 4:] = 0
+        for kw in ({}, {"attention_mask": am}):
+            ref = oracle.whisper_decoder(sd, "decoder.", ids, enc, 2, **kw)
+            got = m.decoder(ids.to(dev), encoder_hidden_states=enc.to(dev), dtype=dtype,
+                            **{k: v.to(dev) for k, v in kw.items()})[0]
+            assert got.shape == ref.shape and max_err(got, ref) < TOL[dtype]
+        ref = oracle.whisper_decoder(sd, "decoder.", ids, None, 2)
+        assert max_err(m.decoder(ids.to(dev), dtype=dtype)[0], ref) < TOL[dtype]
+    # reuse of the encoder projections, and the tied vocabulary projection
+    kv = m.decoder.cross_kv(enc.to(dev), dtype=dtype)
+    h = m.decoder(ids.to(dev), cross_kv=kv, dtype=dtype)[0]
+    ref = oracle.whisper_decoder(sd, "decoder.", ids, enc, 2)
+    assert max_err(h, ref) < TOL[dtype]
+    logits = m.decoder.project_tokens(h)
+    want = ref @ sd["decoder.embed_tokens.weight"].t()
+    assert max_err(logits, want) < TOL[dtype] * max(1.0, want.abs().max().item())
+    with pytest.raises(ValueError):
+        m.decoder(torch.zeros(1, 449, dtype=torch.long, device=dev), dtype=dtype)
+    with pytest.raises(IndexError):
+        m.decoder(torch.full((1, 4), 503, dtype=torch.long, device=dev), dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("training", [False, True])
 def test_visual_frontend(dev, dtype, training):
     m = MoCoVisualFrontend()

@@ -268,6 +268,54 @@ def test_attn_mfma_fwd_bwd(dev, p, B, H, Tq, Tk, masked):
     assert torch.equal(fin, torch.isfinite(lse)) and (lse[fin] - lse2[fin]).abs().max() < 2e-2
 
 
+@pytest.mark.parametrize("Tq,Tk,masked", [(12, 12, False), (200, 200, True), (448, 448, False), (70, 300, True), (1, 129, False)])
+@pytest.mark.parametrize("dtype,use_mfma", [(torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)])
+def test_attn_causal_fwd(dev, Tq, Tk, masked, dtype, use_mfma):
+    """Causal forward (queries = the last Tq positions of the Tk keys), alone and combined with a key mask,
+    against the masked softmax in fp32 on the same (rounded) operands; the log-sum-exp is checked too."""
+    g = torch.Generator().manual_seed(Tq * 7 + Tk)
+    B, H = 2, 3
+    q, k, v = (rnd(g, B, t, H * 64, dtype=dtype) for t in (Tq, Tk, Tk))
+    mask = torch.zeros(B, Tk, dtype=torch.uint8)
+    if masked:
+        mask[1, Tk - Tq + Tq // 2:] = 1                      # padding tokens at the end of one sequence
+        mask[0, 0] = 1
+    qh, kh, vh = (t.float().view(B, -1, H, 64).transpose(1, 2) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) * 0.125
+    future = torch.arange(Tk).view(1, Tk) > torch.arange(Tq).view(Tq, 1) + (Tk - Tq)
+    s = s.masked_fill(future, float("-inf")).masked_fill(mask[:, None, None, :].bool(), float("-inf"))
+    dead = torch.isinf(s).all(-1, keepdim=True)
+    ref = (torch.softmax(s.masked_fill(dead, 0.0), -1).masked_fill(dead, 0.0) @ vh).transpose(1, 2).reshape(B, Tq, H * 64)
+    qd, kd, vd = (t.to(dev, dtype) for t in (q, k, v))
+    o, lse = ops.attn_fwd(qd, kd, vd, H, key_mask=mask.to(dev) if masked else None, scale=0.125, use_mfma=use_mfma,
+                          save_lse=True, causal=True)
+    assert torch.isfinite(o.float()).all()
+    assert rel_err(o, ref) < tol(dtype)
+    want = torch.logsumexp(s, -1)
+    fin = torch.isfinite(want)
+    assert (lse.cpu()[fin] - want[fin]).abs().max() < (1e-3 if dtype == torch.float32 else 2e-2)
+    if Tk > Tq:                                              # more queries than keys has no causal meaning
+        with pytest.raises(RuntimeError):
+            ops.attn_fwd(kd, qd, qd, H, causal=True)
+
+
+def test_embed_tokens(dev):
+    g = torch.Generator().manual_seed(4)
+    V, D, P, B, T = 97, 64, 20, 3, 7
+    table, pos = torch.randn(V, D, generator=g), torch.randn(P, D, generator=g)
+    ids = torch.randint(0, V, (B, T), generator=g)
+    got = ops.embed_tokens(ids.to(dev), table.to(dev), pos.to(dev), past=5)
+    assert torch.equal(got.cpu(), (table[ids] + pos[5:5 + T]).reshape(B * T, D))
+    got = ops.embed_tokens(ids.to(dev), table.to(dev).bfloat16(), pos.to(dev))
+    assert torch.equal(got.cpu(), (table.bfloat16().float()[ids] + pos[:T]).reshape(B * T, D))
+    bad = ids.clone()
+    bad[1, 2] = V
+    with pytest.raises(IndexError):
+        ops.embed_tokens(bad.to(dev), table.to(dev), pos.to(dev))
+    with pytest.raises(RuntimeError):
+        ops.embed_tokens(ids.to(dev), table.to(dev), pos.to(dev), past=P - T + 1)     # runs past the position table
+
+
 @pytest.mark.parametrize("H,W", [(32, 36), (96, 96), (18, 52), (18, 50)])
 @pytest.mark.parametrize("train", [False, True])
 def test_stem_mfma(dev, H, W, train):

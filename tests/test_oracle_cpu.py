@@ -102,6 +102,43 @@ def test_whisper_encoder_matches_transformers_live():
     assert (oracle.whisper_encoder(sd, "", mel, H) - ref).abs().max().item() < 2e-4
 
 
+def _decoder_case():
+    from mocov2_whisper_flamingo_amd import WhisperConfig, WhisperDecoder
+    D, Ly, H, B, T, Te, V = 128, 2, 2, 2, 12, 40, 503
+    cfg = WhisperConfig(d_model=D, decoder_layers=Ly, decoder_attention_heads=H, vocab_size=V, max_target_positions=64)
+    sd = _seeded_sd(WhisperDecoder(cfg), 17)
+    gen = torch.Generator().manual_seed(9)
+    ids = torch.randint(3, V, (B, T), generator=gen)
+    enc = torch.randn(B, Te, D, generator=gen)
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, 9:] = 0
+    return cfg, sd, ids, enc, am, H
+
+
+def test_whisper_decoder_matches_transformers_golden():
+    g = np.load(os.path.join(GOLD, "whisper_decoder.npz"))
+    _, sd, ids, enc, am, H = _decoder_case()
+    assert np.abs(oracle.whisper_decoder(sd, "", ids, enc, H).numpy() - g["y"]).max() < 2e-4
+    assert np.abs(oracle.whisper_decoder(sd, "", ids, enc, H, attention_mask=am).numpy() - g["y_masked"]).max() < 2e-4
+
+
+def test_whisper_decoder_matches_transformers_live():
+    transformers = pytest.importorskip("transformers")
+    cfg, sd, ids, enc, am, H = _decoder_case()
+    hf_cfg = transformers.WhisperConfig(d_model=cfg.d_model, encoder_layers=1, encoder_attention_heads=H,
+                                        encoder_ffn_dim=4 * cfg.d_model, decoder_layers=cfg.decoder_layers,
+                                        decoder_attention_heads=H, decoder_ffn_dim=4 * cfg.d_model, num_mel_bins=80,
+                                        vocab_size=cfg.vocab_size, max_target_positions=64, pad_token_id=0, bos_token_id=1,
+                                        eos_token_id=2, decoder_start_token_id=1, attn_implementation="eager")
+    dec = transformers.WhisperModel(hf_cfg).decoder.eval()
+    dec.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        ref = dec(input_ids=ids, attention_mask=am, encoder_hidden_states=enc, use_cache=False)[0]
+        ref_self_only = dec(input_ids=ids, use_cache=False)[0]
+    assert (oracle.whisper_decoder(sd, "", ids, enc, H, attention_mask=am) - ref).abs().max().item() < 2e-4
+    assert (oracle.whisper_decoder(sd, "", ids, None, H) - ref_self_only).abs().max().item() < 2e-4
+
+
 def test_logmel_matches_feature_extractor():
     g = np.load(os.path.join(GOLD, "logmel.npz"))
     gen = torch.Generator().manual_seed(5)
