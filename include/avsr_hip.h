@@ -114,6 +114,10 @@ int avsr_layernorm_bwd(avsr_stream_t stream, int x_dtype, int g_dtype, const voi
  * use_mfma = 1: bf16 flash kernels on v_mfma_f32_32x32x16_bf16 (the Whisper
  *   encoder self-attention, hf:284-356 / 215-238, and the core of the gated
  *   cross-attention, models/gate_cross_attention.py:40, forward + backward).
+ * use_mfma = 2 (forward only, no dropout): the same flash scheme with both
+ *   products on v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3).  Operands stay bf16 in
+ *   memory; Q/K/V are rounded to fp8 on the way in, the softmax runs in fp32 and
+ *   P is rounded to fp8 (scaled by 128) for the P.V product.
  * use_mfma = 0: exact fp32-math kernels, any dtype.
  * Attention dropout (p_drop > 0) drops softmax probabilities with a
  * counter-based generator: element (row = (b*H+h)*Tq + q, key) uses output

@@ -7,7 +7,11 @@ Keyword-only extensions (defaults keep the reference call valid):
 ``whisper_config`` (the reference hard-codes "openai/whisper-small" and fetches
 it by name; there is no network here, so the architecture is instantiated from
 a config with random weights, or from ``whisper_state`` tensors), ``dtype`` (the
-compute dtype: ``torch.bfloat16`` or ``torch.float32``) and ``device``.
+compute dtype: ``torch.bfloat16`` or ``torch.float32``), ``device``,
+``attention`` ("bf16" or "fp8": the products of the Whisper self-attention on
+e4m3 MFMA) and ``long_form`` (audio of k x 3000 mel frames is encoded as k
+independent 30 s windows whose outputs are concatenated in time; off, such
+input raises ValueError exactly as the reference's encoder does).
 
 There is no CPU path: the module's parameters must live on a GPU and the HIP
 library must be built, otherwise the first call raises.
@@ -30,7 +34,8 @@ logger = logging.getLogger(__name__)
 
 class AVNet(nn.Module):
     def __init__(self, modal, MoCofile, reqInpLen, modelargs, vocab_size, enable_logging=False, *,
-                 whisper_config="small", whisper_state=None, dtype=torch.bfloat16, device=None, seed=0):
+                 whisper_config="small", whisper_state=None, dtype=torch.bfloat16, device=None, seed=0,
+                 attention="bf16", long_form=False):
         super().__init__()
         self.enable_logging = enable_logging
         self.modal = modal
@@ -45,6 +50,10 @@ class AVNet(nn.Module):
             self.whisper_model.load_state_dict(whisper_state, strict=False)
         for p in self.whisper_model.encoder.parameters():      # models/av_net.py:25-26
             p.requires_grad = False
+        if attention not in ("bf16", "fp8") or (attention == "fp8" and dtype != torch.bfloat16):
+            raise ValueError('attention must be "bf16" or "fp8" (fp8 with the bf16 compute dtype only)')
+        self.whisper_model.encoder.attn_fp8 = attention == "fp8"
+        self.long_form = bool(long_form)
 
         d_model = modelargs[0]
         self.audio_proj = nn.Linear(cfg.d_model, d_model)
@@ -101,7 +110,13 @@ class AVNet(nn.Module):
         cdt = self.compute_dtype
         self._step += 1
         # AUDIO: [B,3000,80] is already channels-last, the layout the conv kernel wants
-        channels_last = audioBatch.shape[1] == 3000 and audioBatch.shape[2] == 80
+        channels_last = audioBatch.shape[2] == 80 and audioBatch.shape[1] % 3000 == 0
+        frames = audioBatch.shape[1] if channels_last else audioBatch.shape[2]
+        windows = frames // 3000 if (self.long_form and frames % 3000 == 0) else 1
+        if windows > 1:                                                     # k x 30 s: k encoder windows per clip
+            if not channels_last:
+                audioBatch, channels_last = ops.transpose2d(audioBatch, dtype=cdt), True
+            audioBatch = audioBatch.contiguous().view(audioBatch.shape[0] * windows, 3000, 80)
         # The two frozen encoders are independent until the fusion: the visual frontend runs on a second HIP
         # stream so its many short kernels fill the CUs the audio encoder's GEMM tails leave idle (and vice versa).
         main = torch.cuda.current_stream()
@@ -111,6 +126,8 @@ class AVNet(nn.Module):
             with torch.cuda.stream(side):
                 vis = self.visual_model(videoBatch, videoLen)               # [B,Tv,2048]
         enc = self.whisper_model.encoder(audioBatch, attention_mask=None, dtype=cdt, channels_last=channels_last)[0]
+        if windows > 1:
+            enc = enc.view(enc.shape[0] // windows, windows * enc.shape[1], enc.shape[2])
         if side is not None:
             main.wait_stream(side)
             vis.record_stream(main)

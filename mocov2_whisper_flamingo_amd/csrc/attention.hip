@@ -220,6 +220,182 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
     }
 }
 
+// ---------------------------------------------------------------- fp8 ----
+// Forward with both products on v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3 on gfx950): Q, K, V arrive as bf16 and are
+// rounded to fp8 on the way into registers / LDS; P is rounded to fp8 after the fp32 softmax (scaled by 128 so
+// that probabilities down to 2^-16 of the row maximum survive e4m3's 2^-9 subnormal floor; 128 <= 448 = max
+// finite).  Same transposed scheme as the bf16 kernel: S^T = K.Q^T puts a query in a lane, and the S^T accumulator
+// converted in place is the B operand of O^T = V^T.P^T.  V is staged TRANSPOSED in LDS ([d][key] bytes, row
+// stride 68) so the A operand's eight keys - in the accumulator's register order - are two aligned 4-byte reads.
+#define K8LD 72
+#define V8LD 68
+__device__ __forceinline__ long pack_fp8x8(const float* v) {
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ long bf16x8_to_fp8(const bf16x8& x) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+    return pack_fp8x8(v);
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_fp8_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
+                                                           long ldk, const bf16_t* __restrict__ V, long ldv,
+                                                           bf16_t* __restrict__ O, long ldo, const uint8_t* __restrict__ mask,
+                                                           float* __restrict__ lse, int Tq, int Tk, int H, float scale, int B,
+                                                           int causal) {
+    __shared__ __attribute__((aligned(16))) uint8_t K8[2][64 * K8LD];
+    __shared__ __attribute__((aligned(16))) uint8_t Vt8[2][64 * V8LD];
+    const int qtiles = (Tq + 127) >> 7, npairs = B * H;
+    const int per_xcd = (npairs + 7) >> 3;                         // same XCD-aware 1-D grid as the bf16 kernel
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = xcd * per_xcd + slot / qtiles, qt = slot - (slot / qtiles) * qtiles;
+    if (pair >= npairs || slot >= per_xcd * qtiles) return;
+    const int b = pair / H, h = pair - b * H;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane & 31, hf = lane >> 5;
+    const int q = qt * 128 + wave * 32 + r;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    long qf[4];
+    {
+        const bf16_t* qp = Q + ((long)b * Tq + (q < Tq ? q : 0)) * ldq + h * HD + hf * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = bf16x8_to_fp8(q < Tq ? *(const bf16x8*)(qp + ks * 16) : zero8);
+    }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+    float mrun = -INFINITY, lsum = 0.f;
+    const float sc2 = scale * LOG2E;
+    const int lc = t & 7, lr = t >> 3;
+    const bf16_t* Kb = K + (long)b * Tk * ldk + h * HD;
+    const bf16_t* Vb = V + (long)b * Tk * ldv + h * HD;
+    const uint8_t* mb = mask ? mask + (long)b * Tk : nullptr;
+
+    bf16x8 kreg[2], vreg[2];
+    auto prefetch = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = kv0 + lr + 32 * i;
+            const bool ok = key < Tk;
+            kreg[i] = ok ? *(const bf16x8*)(Kb + (long)key * ldk + lc * 8) : zero8;
+            vreg[i] = ok ? *(const bf16x8*)(Vb + (long)key * ldv + lc * 8) : zero8;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = lr + 32 * i;
+            *(long*)&K8[buf][row * K8LD + lc * 8] = bf16x8_to_fp8(kreg[i]);
+            const unsigned long vb = (unsigned long)bf16x8_to_fp8(vreg[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Vt8[buf][(8 * lc + e) * V8LD + row] = (uint8_t)(vb >> (8 * e));
+        }
+    };
+    const int coff = Tk - Tq;
+    const int kend = causal ? min(Tk, qt * 128 + 128 + coff) : Tk;
+    prefetch(0);
+    stage(0);
+    __syncthreads();
+    for (int kv0 = 0, cur = 0; kv0 < kend; kv0 += 64, cur ^= 1) {
+        const uint8_t* Ks = K8[cur];
+        const uint8_t* Vs = Vt8[cur];
+        const bool more = kv0 + 64 < kend;
+        if (more) prefetch(kv0 + 64);
+
+        f32x16 sacc[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[st][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const long kf = *(const long*)&Ks[(32 * st + r) * K8LD + (2 * ks + hf) * 8];
+                sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kf, qf[ks], sacc[st], 0, 0, 0);
+            }
+        }
+        if (mb || kv0 + 64 > Tk) {
+            const uint64_t dead = dead_keys(mb, kv0, Tk, lane);
+            if (dead) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if ((dead >> (32 * st + (i & 3) + 8 * (i >> 2) + 4 * hf)) & 1) sacc[st][i] = -INFINITY;
+            }
+        }
+        if (causal && kv0 + 63 > qt * 128 + coff) {
+            const int last = q + coff - kv0;
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (32 * st + (i & 3) + 8 * (i >> 2) + 4 * hf > last) sacc[st][i] = -INFINITY;
+        }
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[1][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (__any(mx > mrun)) {
+            const float mnew = fmaxf(mrun, mx);
+            const float alpha = mnew > mrun ? exp2f((mrun - mnew) * sc2) : 1.0f;
+            mrun = mnew;
+            lsum *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+        }
+        const float msc = mrun == -INFINITY ? 0.f : mrun * sc2;
+        float ps = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[st][i], sc2, -msc)); sacc[st][i] = pv * 128.f; ps += pv; }
+        lsum += ps;
+
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = sacc[st][8 * s2 + j];
+                const long pf = pack_fp8x8(pv);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const uint8_t* vp = &Vs[(32 * db + r) * V8LD + 32 * st + 16 * s2 + 4 * hf];
+                    const unsigned lo = *(const unsigned*)vp, hi = *(const unsigned*)(vp + 8);
+                    const long vf = (long)(((unsigned long)hi << 32) | lo);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf, oacc[db], 0, 0, 0);
+                }
+            }
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = lsum > 0.f ? 1.0f / (128.f * lsum) : 0.f;
+    if (q < Tq) {
+        bf16_t* op = O + ((long)b * Tq + q) * ldo + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(oacc[db][4 * g + e] * inv);
+                *(bf16x4*)(op + 32 * db + 8 * g + 4 * hf) = o;
+            }
+        if (lse && hf == 0)
+            lse[((long)b * H + h) * Tq + q] = lsum > 0.f ? mrun * scale + logf(lsum) : INFINITY;
+    }
+}
+
 // dQ for 128 query rows per workgroup (one per lane pair), looping over 64-key tiles; also writes the
 // per-row D = dO.O the dK/dV kernel needs.  Transposed like the forward: S^T = K.Q^T and dP^T = V.dO^T put
 // a query in a lane, and the dS^T accumulator is the B operand of dQ^T = K^T.dS^T.
@@ -665,6 +841,7 @@ extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, cons
                              float p_drop, uint64_t seed, int causal) {
     if (!Q || !K || !V || !O || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return AVSR_EINVAL;
     if (causal && Tk < Tq) return AVSR_EINVAL;
+    if (use_mfma < 0 || use_mfma > 2) return AVSR_EINVAL;
     if (head_dim != HD) return AVSR_EUNSUPPORTED;
     if (B > 65535 || H > 65535) return AVSR_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -675,6 +852,13 @@ extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, cons
         if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) % 16 || (uintptr_t)O % 8) return AVSR_EUNSUPPORTED;
         if (B * H * ((Tq + 127) / 128) > 0x3fffffff) return AVSR_EUNSUPPORTED;
         dim3 grid((unsigned)(8 * ((B * H + 7) / 8) * ((Tq + 127) / 128)));
+        if (use_mfma == 2) {                                  // fp8 products; no dropout form
+            if (p_drop != 0.f) return AVSR_EUNSUPPORTED;
+            hipLaunchKernelGGL(attn_fwd_fp8_kernel, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq, (const bf16_t*)K,
+                               (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse, (int)Tq, (int)Tk,
+                               (int)H, scale, (int)B, causal);
+            return avsr_launch_status();
+        }
         if (p_drop > 0.f)
             hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                                (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,

@@ -193,7 +193,9 @@ def _bthd(t, H):
 
 def attn_fwd(q, k, v, H, *, key_mask=None, scale=1.0, use_mfma=False, save_lse=False, p_drop=0.0, seed=0, causal=False):
     """q: [B,Tq,H*64] view, k/v: [B,Tk,H*64] views (may be column slices of a fused QKV buffer).
-    ``causal``: query i sees keys <= i + (Tk - Tq); forward only (attn_bwd has no causal form)."""
+    ``causal``: query i sees keys <= i + (Tk - Tq); forward only (attn_bwd has no causal form).
+    ``use_mfma``: False = fp32-math kernel, True = bf16 MFMA, "fp8" = e4m3 MFMA products (forward only)."""
+    use_mfma = 2 if use_mfma == "fp8" else int(bool(use_mfma))
     lib = _lib.load()
     _need_cuda(q, k, v, key_mask)
     B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]

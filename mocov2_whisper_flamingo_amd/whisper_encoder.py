@@ -90,6 +90,7 @@ class WhisperEncoder(nn.Module):
         self.layers = nn.ModuleList([_EncoderLayer(d) for _ in range(cfg.encoder_layers)])
         self.layer_norm = nn.LayerNorm(d)
         self._packed = None
+        self.attn_fp8 = False
 
     # ---- weight packing -------------------------------------------------
     def _versions(self, dtype):
@@ -134,11 +135,13 @@ class WhisperEncoder(nn.Module):
 
     # ---- forward ----------------------------------------------------------
     @torch.no_grad()
-    def forward(self, input_features, attention_mask=None, dtype=torch.bfloat16, channels_last=False):
+    def forward(self, input_features, attention_mask=None, dtype=torch.bfloat16, channels_last=False, attn_fp8=None):
         """input_features: [B, n_mels, 3000] (the HF layout) or, with
         ``channels_last``, [B, 3000, n_mels].  ``attention_mask`` is accepted and
         ignored exactly as the HF encoder does (hf:607-609).  Returns a 1-tuple
-        ``([B, 1500, D] in the compute dtype,)`` so that ``encoder(x)[0]`` works."""
+        ``([B, 1500, D] in the compute dtype,)`` so that ``encoder(x)[0]`` works.
+        ``attn_fp8`` (default: the module's ``attn_fp8`` attribute): QK^T and PV of the self-attention
+        on fp8 e4m3 MFMA (bf16 compute dtype only); everything else stays bf16."""
         cfg = self.cfg
         x = input_features
         if not channels_last:
@@ -161,6 +164,10 @@ class WhisperEncoder(nn.Module):
         xs = ops.conv_nhwc(h1, pk["w2"], 1, 3, 2, (0, 1), bias=pk["b2"], act=ops.ACT_GELU, residual=pk["pos"],
                            res_period=Tn, out_dtype=torch.float32).view(B * Tn, D)
         use_mfma = dtype == torch.bfloat16
+        if (self.attn_fp8 if attn_fp8 is None else attn_fp8):
+            if not use_mfma:
+                raise ValueError("fp8 attention needs the bf16 compute dtype")
+            use_mfma = "fp8"
         for lw in pk["layers"]:
             h = ops.layernorm_fwd(xs, *lw["ln1"], out_dtype=dtype)
             qkv = ops.gemm_nt(h, lw["wqkv"], bias=lw["bqkv"]).view(B, Tn, 3 * D)

@@ -22,13 +22,20 @@ def make_padding_mask(lengths, max_length):
 
 
 def avnet_forward(sd, input_batch, whisper_heads, fusion_heads, training=False, new_stats=None,
-                  drop=None, p_drop=0.0, masked_row="nan", return_parts=False):
+                  drop=None, p_drop=0.0, masked_row="nan", return_parts=False, long_form=False):
     """``AVNet.forward``.  ``input_batch`` = (audio, audio_mask, video, video_mask,
-    video_len).  ``video_len`` is clamped in place, as the reference does."""
+    video_len).  ``video_len`` is clamped in place, as the reference does.
+    ``long_form`` (no counterpart in the reference, whose encoder rejects anything but 3000
+    frames): audio of k x 3000 frames is cut into k windows, each goes through the
+    reference encoder on its own, and the outputs are concatenated in time."""
     audio, audio_mask, video, _video_mask, video_len = input_batch
-    if audio.shape[1] == 3000 and audio.shape[2] == 80:
+    if audio.shape[2] == 80 and audio.shape[1] % 3000 == 0:
         audio = audio.transpose(1, 2)
-    enc = whisper_encoder(sd, "whisper_model.encoder.", audio, whisper_heads)
+    if long_form and audio.shape[2] > 3000:
+        enc = torch.cat([whisper_encoder(sd, "whisper_model.encoder.", w, whisper_heads)
+                         for w in audio.split(3000, dim=2)], dim=1)
+    else:
+        enc = whisper_encoder(sd, "whisper_model.encoder.", audio, whisper_heads)
     a = layer_norm_fp32(F.linear(enc, sd["audio_proj.weight"], sd["audio_proj.bias"]),
                         sd["audio_ln.weight"], sd["audio_ln.bias"])
     a = positional_encoding(a, sd["pos_enc_audio.pe"])
@@ -64,7 +71,7 @@ def ctc_ce_loss(logits, target_ids, input_lengths, target_lengths, label_smoothi
 
 
 def training_step(sd, batch, whisper_heads, fusion_heads, training=False, label_smoothing=0.1,
-                  drop=None, p_drop=0.0, masked_row="nan"):
+                  drop=None, p_drop=0.0, masked_row="nan", long_form=False):
     """``AVSRModule.training_step`` (train.py:143-170) followed by backward.
     Returns (loss, ctc, ce, logits, grads) with grads keyed like ``sd`` for the
     parameters autograd reaches."""
@@ -76,7 +83,7 @@ def training_step(sd, batch, whisper_heads, fusion_heads, training=False, label_
            batch["video_lengths"].clone())
     new_stats = {} if training else None
     logits = avnet_forward(leaf, inp, whisper_heads, fusion_heads, training, new_stats, drop,
-                           p_drop, masked_row)
+                           p_drop, masked_row, long_form=long_form)
     ctc, ce = ctc_ce_loss(logits, batch["target_ids"], batch["audio_lengths"],
                           batch["target_lengths"].reshape(-1), label_smoothing)
     loss = ctc + ce

@@ -165,6 +165,37 @@ def _micro_avnet(dtype, dev, vocab=503, p_drop=0.1):
     return m.to(dev), sd
 
 
+@pytest.mark.parametrize("dtype,attention", [(torch.float32, "bf16"), (torch.bfloat16, "bf16"), (torch.bfloat16, "fp8")])
+def test_avnet_long_form_chunked_encoder(dev, dtype, attention):
+    """60 s clips: 6000 mel frames are encoded as two independent 30 s windows and concatenated (3000 encoder
+    frames), so all 20 video frames survive the truncation; checked against the oracle doing the same with the
+    reference encoder per window.  Without long_form the 6000-frame input raises as the reference encoder does.
+    attention="fp8" runs the encoder's QK^T / PV on e4m3 MFMA: tolerance 5e-2 (three mantissa bits per operand)."""
+    m = AVNet("audiovisual", None, 96, (128, 2, 4, 3000, 512, 0.1), 503, whisper_config=MICRO, dtype=dtype,
+              attention=attention, long_form=True)
+    sd = seed_module(m, 21)
+    m.to(dev).eval()
+    batch = synthetic_batch(B=2, Tv=20, H=32, W=32, L=4, vocab=503, seed=5)
+    g = torch.Generator().manual_seed(6)
+    audio = torch.randn(2, 6000, 80, generator=g)
+    mask = torch.ones(2, 6000, dtype=torch.bool)
+    inp = (audio, mask, batch["video"], batch["video_mask"], batch["video_lengths"].clone())
+    ref = oracle.avnet_forward(sd, inp, 2, 2, masked_row="zero", long_form=True)
+    assert ref.shape[1] == 20
+    tol_ = 5e-2 if attention == "fp8" else TOL[dtype]
+    for a in (audio, audio.transpose(1, 2).contiguous()):
+        got = m((a.to(dev), mask.to(dev), batch["video"].to(dev), batch["video_mask"].to(dev),
+                 batch["video_lengths"].clone().to(dev)))
+        assert got.shape == ref.shape and max_err(got, ref) < tol_
+    m.long_form = False
+    with pytest.raises(ValueError):
+        m((audio.to(dev), mask.to(dev), batch["video"].to(dev), batch["video_mask"].to(dev),
+           batch["video_lengths"].clone().to(dev)))
+    with pytest.raises(ValueError):
+        AVNet("audiovisual", None, 96, (128, 2, 4, 3000, 512, 0.1), 503, whisper_config=MICRO, dtype=torch.float32,
+              attention="fp8")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_avnet_forward_and_training_step(dev, dtype):
     m, sd = _micro_avnet(dtype, dev)

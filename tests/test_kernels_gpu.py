@@ -299,6 +299,49 @@ def test_attn_causal_fwd(dev, Tq, Tk, masked, dtype, use_mfma):
             ops.attn_fwd(kd, qd, qd, H, causal=True)
 
 
+@pytest.mark.parametrize("Tq,Tk,masked,causal", [(1500, 1500, False, False), (75, 75, True, False), (130, 257, True, False),
+                                                  (448, 448, False, True)])
+def test_attn_fp8_fwd(dev, Tq, Tk, masked, causal):
+    """fp8 (e4m3) MFMA forward.  Two checks: tight against an emulation that rounds Q, K, V and the scaled
+    probabilities to e4m3 exactly where the kernel does (so the MFMA data path, masks and layout are right),
+    and loose against exact attention on the bf16 operands - the accuracy a caller trades for the format (three
+    mantissa bits per operand; on random data the output is an average of up to 1500 values, so it is small
+    against the rounding noise: 15 % of the output maximum is the bound here, the network-level effect is
+    checked in test_avnet_long_form_chunked_encoder)."""
+    g = torch.Generator().manual_seed(Tq + 3 * Tk)
+    B, H = 2, 3
+    q, k, v = (rnd(g, B, t, H * 64, dtype=torch.bfloat16) for t in (Tq, Tk, Tk))
+    q = q * 0.125
+    mask = torch.zeros(B, Tk, dtype=torch.uint8)
+    if masked:
+        mask[1, Tk // 2:] = 1
+        mask[0, 5] = 1
+    f8 = lambda t: t.to(torch.float8_e4m3fn).float()
+    def attn(qx, kx, vx, quant_p):
+        qh, kh, vh = (t.float().view(B, -1, H, 64).transpose(1, 2) for t in (qx, kx, vx))
+        s = qh @ kh.transpose(-1, -2)
+        if causal:
+            s = s.masked_fill(torch.arange(Tk).view(1, Tk) > torch.arange(Tq).view(Tq, 1) + (Tk - Tq), float("-inf"))
+        s = s.masked_fill(mask[:, None, None, :].bool(), float("-inf"))
+        p = torch.exp(s - s.amax(-1, keepdim=True))
+        l = p.sum(-1, keepdim=True)
+        if quant_p:
+            p = f8(p * 128.0) / 128.0
+        return ((p @ vh) / l).transpose(1, 2).reshape(B, Tq, H * 64), torch.logsumexp(s, -1)
+    emu, lse_emu = attn(f8(q), f8(k), f8(v), True)
+    exact, _ = attn(q, k, v, False)
+    qd, kd, vd = (t.to(dev, torch.bfloat16) for t in (q, k, v))
+    o, lse = ops.attn_fwd(qd, kd, vd, H, key_mask=mask.to(dev) if masked else None, scale=1.0, use_mfma="fp8",
+                          save_lse=True, causal=causal)
+    assert torch.isfinite(o.float()).all()
+    print("fp8 attention error vs emulation / vs exact:", rel_err(o, emu), rel_err(o, exact))
+    assert rel_err(o, emu) < 4e-2          # differs by where the running maximum stood when P was rounded
+    assert rel_err(o, exact) < 0.15
+    assert (lse.cpu() - lse_emu).abs().max() < 2e-2
+    with pytest.raises(RuntimeError):
+        ops.attn_fwd(qd, kd, vd, H, use_mfma="fp8", p_drop=0.1, seed=1)
+
+
 def test_embed_tokens(dev):
     g = torch.Generator().manual_seed(4)
     V, D, P, B, T = 97, 64, 20, 3, 7
