@@ -166,6 +166,21 @@ int avsr_logmel_fwd(avsr_stream_t stream, int variant, int out_dtype, const floa
                     int64_t n_samples, int64_t n_valid, int64_t batch, const float* dft_table,
                     const float* mel_table, void* out, int64_t out_stride_b, int64_t out_stride_t,
                     int64_t out_stride_m, int64_t n_frames_out, float* workspace);
+/* Training-time form of the AVSR_MEL_SPEC_LN variant (datamodule/transforms.py:122-132): between the mel
+ * bank and the clip layer norm it applies SpecAugment (transforms.py:144-179: per clip two frequency bands
+ * of freq_width bins and two time bands of time_width frames set to zero; starts in freq_start / time_start,
+ * device int32 [batch,2], a negative start = band not drawn, either pointer may be NULL) and AddNoise
+ * (transforms.py:47-59 with torchaudio.functional.add_noise: mel row m += sqrt(E_m / E_noise) * 10^(-snr/20)
+ * * noise, E = sum of squares over the frames; noise: fp32, n_frames_out values per clip at
+ * noise + clip * noise_stride (stride 0 = one segment for all clips); snr_db: device fp32 [batch]).
+ * The random draws are the host's.  workspace: avsr_logmel_augment_workspace_floats() floats. */
+int64_t avsr_logmel_augment_workspace_floats(int64_t batch, int64_t n_frames_out);
+int avsr_logmel_augment_fwd(avsr_stream_t stream, int out_dtype, const float* wave, int64_t wave_stride,
+                            int64_t n_samples, int64_t n_valid, int64_t batch, const float* dft_table,
+                            const float* mel_table, void* out, int64_t out_stride_b, int64_t out_stride_t,
+                            int64_t out_stride_m, int64_t n_frames_out, float* workspace,
+                            const int32_t* freq_start, int64_t freq_width, const int32_t* time_start,
+                            int64_t time_width, const float* noise, int64_t noise_stride, const float* snr_db);
 
 /* ------------------------------------------------------------------------
  * Visual frontend pieces (models/moco_visual_frontend.py).
@@ -196,6 +211,15 @@ int avsr_maxpool3x3s2(avsr_stream_t stream, int in_dtype, int out_dtype, const v
                       const float* scale, const float* shift, int64_t N, int64_t H, int64_t W, int64_t C);
 int avsr_avgpool_mask_fwd(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y,
                           const int64_t* lens, int64_t B, int64_t T, int64_t HW, int64_t C);
+/* VideoTransform of the data path (datamodule/transforms.py:61-96) for frames already in device memory:
+ * video [B,T,3,H,W] uint8 (in_is_u8 = 1) or fp32 with values 0..255 -> out fp32 [B,T,3,OH,OW]:
+ * bilinear resize (interpolate align_corners=False, :66-68; OH=H, OW=W copies), /255, horizontal flip of the
+ * clips with flip[b] != 0 (:70), frames with frame_zero[b*T+t] != 0 zeroed (AdaptiveTimeMask, :27-45,73), then
+ * (x - mean[c]) / std[c] (:74,95).  flip / frame_zero: device uint8, may be NULL; mean3 / std3: HOST float[3].
+ * The random draws are the host's; ColorJitter / RandomGrayscale (:71-72) are not part of it. */
+int avsr_video_preprocess(avsr_stream_t stream, int in_is_u8, const void* video, float* out, int64_t B, int64_t T,
+                          int64_t H, int64_t W, int64_t OH, int64_t OW, const uint8_t* flip,
+                          const uint8_t* frame_zero, const float* mean3, const float* std3);
 /* sum / sumsq: [nparts, C] partial-sum slabs; ws: avsr_bn_finalize_workspace_floats(C) floats,
  * needed when nparts > 32 */
 int64_t avsr_bn_finalize_workspace_floats(int64_t C);

@@ -257,6 +257,83 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(const float* __res
     }
 }
 
+// ---- training-time augmentation of the mel-spectrogram variant (datamodule/transforms.py:122-132) ----
+// SpecAugment (:144-179): two frequency bands of `fw` bins and two time bands of `tw` frames set to zero, then
+// AddNoise (:47-59), which the reference applies to the [80, frames] mel as if its rows were audio channels:
+// row m becomes x_m + scale_m * noise with scale_m = sqrt(E(x_m) / E(noise)) * 10^(-snr/20) (the
+// torchaudio.functional.add_noise formula), E = sum of squares over the frames.  A row that is entirely
+// zero gets no noise (its energy is 0).  The band starts, the noise segment and the SNR are drawn by the host.
+__device__ __forceinline__ bool lm_banded(int x, const int* start, int width) {
+    return (start[0] >= 0 && x >= start[0] && x < start[0] + width) || (start[1] >= 0 && x >= start[1] && x < start[1] + width);
+}
+
+// One workgroup of 960 threads (12 frame lanes x 80 mel bins) per clip: energies[b][0..79] = per-bin energy of
+// the masked mel, energies[b][80] = energy of the noise segment.  Plain stores, fixed order: deterministic.
+__global__ __launch_bounds__(960) void mel_aug_energy_kernel(const float* __restrict__ raw, const float* __restrict__ noise,
+                                                             long noise_stride, const int* __restrict__ fstart, int fw,
+                                                             const int* __restrict__ tstart, int tw, int T,
+                                                             float* __restrict__ energies) {
+    __shared__ float red[12 * 81];
+    const int b = blockIdx.x, tid = threadIdx.x, m = tid % LM_NMEL, tr = tid / LM_NMEL;
+    const int fs[2] = {fstart ? fstart[2 * b] : -1, fstart ? fstart[2 * b + 1] : -1};
+    const int ts[2] = {tstart ? tstart[2 * b] : -1, tstart ? tstart[2 * b + 1] : -1};
+    const bool mdead = lm_banded(m, fs, fw);
+    const float* x = raw + (long)b * T * LM_NMEL;
+    float e = 0.f, en = 0.f;
+    for (int t = tr; t < T; t += 12) {
+        const float v = (mdead || lm_banded(t, ts, tw)) ? 0.f : x[(long)t * LM_NMEL + m];
+        e = fmaf(v, v, e);
+    }
+    if (m == 0)
+        for (int t = tr; t < T; t += 12) { const float n = noise[(long)b * noise_stride + t]; en = fmaf(n, n, en); }
+    red[tr * 81 + m] = e;
+    if (m == 0) red[tr * 81 + 80] = en;
+    __syncthreads();
+    if (tid < 81) {
+        float a = 0.f;
+        for (int i = 0; i < 12; ++i) a += red[i * 81 + tid];
+        energies[b * 81 + tid] = a;
+    }
+}
+
+// raw <- masked(raw) + scale_m * noise[t]; per-workgroup sum / sum of squares for the clip layer norm, in the slab
+// layout logmel_finalize_kernel reads (one entry per LM_FR frames).
+__global__ __launch_bounds__(256) void mel_aug_apply_kernel(float* __restrict__ raw, const float* __restrict__ noise,
+                                                            long noise_stride, const int* __restrict__ fstart, int fw,
+                                                            const int* __restrict__ tstart, int tw, int T,
+                                                            const float* __restrict__ energies, const float* __restrict__ snr_db,
+                                                            float* __restrict__ slab) {
+    __shared__ float scale[LM_NMEL];
+    __shared__ float red[8];
+    const int b = blockIdx.y, tid = threadIdx.x, t0 = blockIdx.x * LM_FR;
+    const int fs[2] = {fstart ? fstart[2 * b] : -1, fstart ? fstart[2 * b + 1] : -1};
+    const int ts[2] = {tstart ? tstart[2 * b] : -1, tstart ? tstart[2 * b + 1] : -1};
+    if (tid < LM_NMEL) {
+        const float es = energies[b * 81 + tid], en = energies[b * 81 + 80];
+        scale[tid] = es > 0.f ? sqrtf(es / en) * exp10f(-snr_db[b] * 0.05f) : 0.f;
+    }
+    __syncthreads();
+    float s0 = 0.f, s1 = 0.f;
+    float* x = raw + ((long)b * T + t0) * LM_NMEL;
+    const int n = min(LM_FR, T - t0) * LM_NMEL;
+    for (int i = tid; i < n; i += 256) {
+        const int tt = i / LM_NMEL, m = i - tt * LM_NMEL, t = t0 + tt;
+        float v = (lm_banded(m, fs, fw) || lm_banded(t, ts, tw)) ? 0.f : x[i];
+        v = fmaf(scale[m], noise[(long)b * noise_stride + t], v);
+        x[i] = v;
+        s0 += v;
+        s1 = fmaf(v, v, s1);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s0; red[(tid >> 6) * 2 + 1] = s1; }
+    __syncthreads();
+    if (tid == 0) {
+        float* o = slab + ((long)b * gridDim.x + blockIdx.x) * 2;
+        o[0] = red[0] + red[2] + red[4] + red[6];
+        o[1] = red[1] + red[3] + red[5] + red[7];
+    }
+}
+
 inline int lm_nblk(int n_frames_out) { return (n_frames_out + LM_FR - 1) / LM_FR; }
 
 }  // namespace
@@ -322,5 +399,44 @@ extern "C" int avsr_logmel_fwd(avsr_stream_t stream, int variant, int out_dtype,
                                nblk, (int)n_frames_out, (bf16_t*)out, (long)out_stride_b, (long)out_stride_t,
                                (long)out_stride_m);
     }
+    return avsr_launch_status();
+}
+
+extern "C" int64_t avsr_logmel_augment_workspace_floats(int64_t batch, int64_t n_frames_out) {
+    if (batch <= 0 || n_frames_out <= 0) return 0;
+    return avsr_logmel_workspace_floats(batch, n_frames_out) + batch * 81;
+}
+
+extern "C" int avsr_logmel_augment_fwd(avsr_stream_t stream, int out_dtype, const float* wave, int64_t wave_stride,
+                                       int64_t n_samples, int64_t n_valid, int64_t batch, const float* dft_table,
+                                       const float* mel_table, void* out, int64_t out_stride_b, int64_t out_stride_t,
+                                       int64_t out_stride_m, int64_t n_frames_out, float* workspace,
+                                       const int32_t* freq_start, int64_t freq_width, const int32_t* time_start,
+                                       int64_t time_width, const float* noise, int64_t noise_stride, const float* snr_db) {
+    if (!wave || !dft_table || !mel_table || !out || !workspace || !noise || !snr_db) return AVSR_EINVAL;
+    if (batch <= 0 || n_frames_out <= 0 || n_valid < 0 || n_valid > n_samples || wave_stride < n_valid) return AVSR_EINVAL;
+    if (freq_width < 0 || time_width < 0 || (noise_stride != 0 && noise_stride < n_frames_out)) return AVSR_EINVAL;
+    if (out_dtype != AVSR_F32 && out_dtype != AVSR_BF16) return AVSR_EINVAL;
+    if (n_samples <= LM_NFFT / 2 || n_samples > (1 << 30) || batch > 65535) return AVSR_EUNSUPPORTED;
+    int n_frames = (int)(1 + n_samples / LM_HOP);
+    if (n_frames > n_frames_out) n_frames = (int)n_frames_out;
+    const int nblk = lm_nblk((int)n_frames_out), T = (int)n_frames_out;
+    float* raw = workspace;
+    float* slab = workspace + batch * n_frames_out * LM_NMEL;
+    float* energies = slab + batch * nblk * 2;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblk, (unsigned)batch), fgrid((T + LM_FIN_FR - 1) / LM_FIN_FR, (unsigned)batch);
+    hipLaunchKernelGGL(logmel_dft_mel_kernel<AVSR_MEL_SPEC_LN>, grid, dim3(256), 0, s, wave, (long)wave_stride,
+                       (int)n_samples, (int)n_valid, n_frames, T, dft_table, mel_table, raw, slab);
+    hipLaunchKernelGGL(mel_aug_energy_kernel, dim3((unsigned)batch), dim3(960), 0, s, raw, noise, (long)noise_stride,
+                       freq_start, (int)freq_width, time_start, (int)time_width, T, energies);
+    hipLaunchKernelGGL(mel_aug_apply_kernel, grid, dim3(256), 0, s, raw, noise, (long)noise_stride, freq_start,
+                       (int)freq_width, time_start, (int)time_width, T, energies, snr_db, slab);
+    if (out_dtype == AVSR_F32)
+        hipLaunchKernelGGL((logmel_finalize_kernel<AVSR_MEL_SPEC_LN, float>), fgrid, dim3(256), 0, s, raw, slab, nblk, T,
+                           (float*)out, (long)out_stride_b, (long)out_stride_t, (long)out_stride_m);
+    else
+        hipLaunchKernelGGL((logmel_finalize_kernel<AVSR_MEL_SPEC_LN, bf16_t>), fgrid, dim3(256), 0, s, raw, slab, nblk, T,
+                           (bf16_t*)out, (long)out_stride_b, (long)out_stride_t, (long)out_stride_m);
     return avsr_launch_status();
 }

@@ -349,6 +349,43 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
 
 // Global average pool over HW pixels of an NHWC tensor [B*T, HW, C] -> [B*T, C];
 // frames t >= len[b] are written as zeros (moco_visual_frontend.py:42,49).
+// VideoTransform of the data path (datamodule/transforms.py:61-96) for frames already on the GPU: optional bilinear
+// resize with the half-pixel centres of interpolate(align_corners=False) (:66-68), /255 (:69,94), optional
+// horizontal flip per clip (:70), optional zeroing of whole frames (AdaptiveTimeMask, :27-45,73, applied before
+// the normalisation as the reference orders it), then (x - mean[c]) / std[c] (:74,95).  One thread per output pixel.
+template <typename TI>
+__global__ __launch_bounds__(256) void video_preprocess_kernel(const TI* __restrict__ in, float* __restrict__ out, long n, int T,
+                                                               int H, int W, int OH, int OW, const uint8_t* __restrict__ flip,
+                                                               const uint8_t* __restrict__ frame_zero, float m0, float m1,
+                                                               float m2, float i0, float i1, float i2) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const float sy = (float)H / OH, sx = (float)W / OW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), c = (int)((i / ((long)OW * OH)) % 3);
+        const long f = i / ((long)OW * OH * 3);                 // frame index b*T + t
+        const int b = (int)(f / T);
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), istd = c == 0 ? i0 : (c == 1 ? i1 : i2);
+        float v = 0.f;
+        if (!(frame_zero && frame_zero[f])) {
+            const int xs = (flip && flip[b]) ? OW - 1 - ox : ox;
+            const TI* src = in + (f * 3 + c) * (long)H * W;
+            if (OH == H && OW == W) {
+                v = (float)src[(long)oy * W + xs];
+            } else {
+                const float fy = fmaxf((oy + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf((xs + 0.5f) * sx - 0.5f, 0.f);
+                const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+                const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+                const float wy = fy - y0, wx = fx - x0;
+                const float a = (float)src[(long)y0 * W + x0], bq = (float)src[(long)y0 * W + x1];
+                const float cq = (float)src[(long)y1 * W + x0], d = (float)src[(long)y1 * W + x1];
+                v = (1.f - wy) * ((1.f - wx) * a + wx * bq) + wy * ((1.f - wx) * cq + wx * d);
+            }
+            v = v / 255.0f;
+        }
+        out[i] = (v - mean) * istd;
+    }
+}
+
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void avgpool_mask_kernel(const T* __restrict__ x, TO* __restrict__ y,
                                                            const int64_t* __restrict__ lens, int Tn, int HW, int C) {
@@ -451,6 +488,26 @@ extern "C" int avsr_maxpool3x3s2(avsr_stream_t stream, int in_dtype, int out_dty
     else if (in_dtype == AVSR_F32 && out_dtype == AVSR_BF16) L(float, bf16_t);
     else return AVSR_EINVAL;
 #undef L
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_video_preprocess(avsr_stream_t stream, int in_is_u8, const void* video, float* out, int64_t B, int64_t T,
+                                     int64_t H, int64_t W, int64_t OH, int64_t OW, const uint8_t* flip,
+                                     const uint8_t* frame_zero, const float* mean3, const float* std3) {
+    if (!video || !out || !mean3 || !std3 || B <= 0 || T <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return AVSR_EINVAL;
+    if (std3[0] == 0.f || std3[1] == 0.f || std3[2] == 0.f) return AVSR_EINVAL;
+    if (B * T > (1 << 30) || H > 16384 || W > 16384 || OH > 16384 || OW > 16384) return AVSR_EUNSUPPORTED;
+    const long n = (long)B * T * 3 * OH * OW;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)std::min<long>((n + 255) / 256, 16384)), block(256);
+    if (in_is_u8)
+        hipLaunchKernelGGL(video_preprocess_kernel<uint8_t>, grid, block, 0, s, (const uint8_t*)video, out, n, (int)T, (int)H,
+                           (int)W, (int)OH, (int)OW, flip, frame_zero, mean3[0], mean3[1], mean3[2], 1.f / std3[0],
+                           1.f / std3[1], 1.f / std3[2]);
+    else
+        hipLaunchKernelGGL(video_preprocess_kernel<float>, grid, block, 0, s, (const float*)video, out, n, (int)T, (int)H,
+                           (int)W, (int)OH, (int)OW, flip, frame_zero, mean3[0], mean3[1], mean3[2], 1.f / std3[0],
+                           1.f / std3[1], 1.f / std3[2]);
     return avsr_launch_status();
 }
 

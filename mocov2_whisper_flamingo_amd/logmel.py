@@ -6,8 +6,14 @@ a waveform of up to 30 s is read as zero-padded to 480 000 samples and becomes
 ``[B, 80, 3000]`` log-mel features.  ``LogMelFrontend("melspec_norm")`` stands in for
 ``AudioTransform``'s evaluation pipeline (datamodule/transforms.py:115-121,134-142):
 torchaudio's ``MelSpectrogram`` -> pad/trim to 3000 frames -> whole-clip layer norm,
-returned as ``[B, 3000, 80]`` like the pipeline's transpose does.
+returned as ``[B, 3000, 80]`` like the pipeline's transpose does;
+``LogMelFrontend("melspec_norm").train(...)`` is its training pipeline
+(transforms.py:122-132): SpecAugment bands and babble noise at a random SNR between
+the mel bank and the layer norm, with the random draws made on the host as the
+reference does.
 """
+import random
+
 import torch
 
 from . import ops
@@ -45,3 +51,33 @@ class LogMelFrontend:
             out = ops.logmel_fwd(wave.contiguous(), self.tables, self.code, n_frames=self.N_FRAMES,
                                  out_dtype=dtype, channels_last=channels_last)
         return out[0] if squeeze else out
+
+    SNR_LEVELS = (-5, 0, 5, 10, 15, 20, 999999)          # transforms.py:50
+
+    def draw(self, batch, n_samples, noise_len, rng=random):
+        """The random choices of one training batch, drawn as transforms.py:55-57,163,176 draw them: two
+        frequency-band starts in [0, 80-48), two time-band starts in [0, frames - frames//8) over the un-padded
+        frame count, a start offset into the noise recording and an SNR level per clip."""
+        frames = 1 + n_samples // 160
+        tw = frames // 8
+        fs = [[rng.randrange(0, 80 - 48) for _ in range(2)] for _ in range(batch)]
+        ts = [[rng.randrange(0, frames - tw) if frames - tw > 0 else -1 for _ in range(2)] for _ in range(batch)]
+        off = [rng.randint(0, noise_len - self.N_FRAMES) for _ in range(batch)]
+        snr = [float(rng.choice(self.SNR_LEVELS)) for _ in range(batch)]
+        return fs, ts, off, snr
+
+    def train(self, wave, noise_recording, *, draws=None, rng=random, dtype=torch.float32, channels_last=True):
+        """wave [B, n] fp32 on the GPU, ``noise_recording`` a 1-D fp32 GPU tensor of at least 3000 values (the
+        reference slices 3000 consecutive samples of babble_noise.wav and adds them to the mel rows).
+        ``draws`` = (freq_starts, time_starts, noise_offsets, snr_db) overrides the random choices."""
+        if self.code != ops.MEL_SPEC_LN:
+            raise ValueError('the training pipeline belongs to the "melspec_norm" variant')
+        B, n = wave.shape
+        fs, ts, off, snr = draws if draws is not None else self.draw(B, n, noise_recording.numel(), rng)
+        dev = wave.device
+        noise = torch.stack([noise_recording[o:o + self.N_FRAMES] for o in off]).contiguous()
+        return ops.logmel_augment_fwd(wave.contiguous(), self.tables, noise=noise,
+                                      snr_db=torch.tensor(snr, dtype=torch.float32, device=dev),
+                                      freq_start=torch.tensor(fs, dtype=torch.int32, device=dev),
+                                      time_start=torch.tensor(ts, dtype=torch.int32, device=dev),
+                                      n_frames=self.N_FRAMES, out_dtype=dtype, channels_last=channels_last)

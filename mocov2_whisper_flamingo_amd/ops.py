@@ -298,6 +298,61 @@ def logmel_fwd(wave, tables, variant, *, n_samples=None, n_frames=None, out_dtyp
     return out
 
 
+def logmel_augment_fwd(wave, tables, *, noise, snr_db, freq_start=None, time_start=None, freq_width=48, time_width=None,
+                       n_frames=3000, out_dtype=torch.float32, channels_last=True):
+    """Training-time mel-spectrogram pipeline: mel power -> SpecAugment bands -> noise at a target SNR per mel
+    row -> clip layer norm.  wave [B,n] fp32; noise [B,n_frames] or [n_frames] fp32; snr_db [B] fp32;
+    freq_start / time_start int32 [B,2] (negative = no band).  ``time_width`` defaults to the reference's
+    (1 + n // 160) // 8."""
+    lib = _lib.load()
+    _need_cuda(wave, noise, snr_db, freq_start, time_start, *tables)
+    if wave.dim() != 2 or wave.dtype != torch.float32 or wave.stride(1) != 1:
+        raise ValueError("logmel expects a [B, n] fp32 waveform with unit sample stride")
+    B, n = wave.shape
+    if noise.dtype != torch.float32 or noise.shape[-1] != n_frames or noise.stride(-1) != 1:
+        raise ValueError("noise must be fp32 with n_frames values per clip")
+    if noise.dim() == 2 and noise.shape[0] != B:
+        raise ValueError("noise must be [n_frames] or [B, n_frames]")
+    if snr_db.dtype != torch.float32 or snr_db.numel() != B:
+        raise ValueError("snr_db must be fp32 [B]")
+    for st_ in (freq_start, time_start):
+        if st_ is not None and (st_.dtype != torch.int32 or tuple(st_.shape) != (B, 2) or not st_.is_contiguous()):
+            raise ValueError("band starts must be contiguous int32 [B,2]")
+    if time_width is None:
+        time_width = (1 + n // 160) // 8
+    shape = (B, n_frames, 80) if channels_last else (B, 80, n_frames)
+    out = torch.empty(shape, dtype=out_dtype, device=wave.device)
+    st, sm = (80, 1) if channels_last else (1, n_frames)
+    ws = torch.empty(int(lib.avsr_logmel_augment_workspace_floats(B, n_frames)), dtype=torch.float32, device=wave.device)
+    check(lib.avsr_logmel_augment_fwd(_stream(), _DT[out_dtype], wave.data_ptr(), wave.stride(0), n, n, B,
+                                      tables[0].data_ptr(), tables[1].data_ptr(), out.data_ptr(), 80 * n_frames, st, sm,
+                                      n_frames, ws.data_ptr(), _p(freq_start), freq_width, _p(time_start), time_width,
+                                      noise.data_ptr(), noise.stride(0) if noise.dim() == 2 else 0,
+                                      snr_db.contiguous().data_ptr()), "avsr_logmel_augment_fwd")
+    return out
+
+
+def video_preprocess(video, *, size=None, flip=None, frame_zero=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """video [B,T,3,H,W] uint8 or fp32 (0..255) -> fp32 [B,T,3,OH,OW]: resize (``size`` = (OH, OW) or None),
+    /255, per-clip horizontal flip (uint8 [B]), zeroed frames (uint8 [B,T]), ImageNet normalisation."""
+    import ctypes
+    lib = _lib.load()
+    _need_cuda(video, flip, frame_zero)
+    if video.dim() != 5 or video.shape[2] != 3 or not video.is_contiguous() or video.dtype not in (torch.uint8, torch.float32):
+        raise ValueError("video must be a contiguous [B,T,3,H,W] uint8 or fp32 tensor")
+    B, T, _, H, W = video.shape
+    OH, OW = size if size is not None else (H, W)
+    for m_, shp in ((flip, (B,)), (frame_zero, (B, T))):
+        if m_ is not None and (m_.dtype != torch.uint8 or tuple(m_.shape) != shp or not m_.is_contiguous()):
+            raise ValueError("flip must be uint8 [B] and frame_zero uint8 [B,T], contiguous")
+    out = torch.empty((B, T, 3, OH, OW), dtype=torch.float32, device=video.device)
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    check(lib.avsr_video_preprocess(_stream(), int(video.dtype == torch.uint8), video.data_ptr(), out.data_ptr(), B, T, H, W,
+                                    OH, OW, _p(flip), _p(frame_zero), ctypes.cast(m3, ctypes.c_void_p),
+                                    ctypes.cast(s3, ctypes.c_void_p)), "avsr_video_preprocess")
+    return out
+
+
 def maxpool3x3s2(x, *, scale=None, shift=None, out_dtype=None):
     lib = _lib.load()
     N, H, W, C = x.shape

@@ -21,7 +21,7 @@ Pinning status
   ``transformers`` implementation the reference constructs / calls
   (``models/av_net.py:22,78``), live in ``tests/test_oracle_cpu.py`` and
   through goldens.
-* ResNet-50 trunk, 3D stem, torchaudio MelSpectrogram variant: PARITY UNPINNED -
+* ResNet-50 trunk, 3D stem, torchaudio MelSpectrogram variant and its add_noise: PARITY UNPINNED -
   ``torchvision`` / ``torchaudio`` are not installed, and the reference holds no
   fixtures for them; the restatement follows the published architecture and is
   self-checked against ``torch.nn.functional`` convolution / batch-norm.
@@ -31,4 +31,4 @@ from .ref_fusion import (layer_norm_fp32, positional_encoding, gated_block,
 from .ref_whisper import whisper_encoder, whisper_decoder
 from .ref_visual import visual_frontend
 from .ref_avnet import avnet_forward, ctc_ce_loss, training_step, make_padding_mask
-from .ref_logmel import whisper_logmel, torchaudio_melspec_norm
+from .ref_logmel import whisper_logmel, torchaudio_melspec_norm, torchaudio_melspec_train

@@ -95,3 +95,45 @@ def torchaudio_melspec_norm(wave, target_len=3000):
         mel = mel[..., :target_len]
     x = mel.transpose(1, 2)                                               # [B,T,80]
     return torch.stack([F.layer_norm(xi, xi.shape, eps=1e-8) for xi in x])
+
+
+def spec_augment(mel_tf, freq_starts, time_starts, freq_width=48):
+    """``AudioTransform._apply_spec_augment`` (transforms.py:144-179) on one [frames, 80] clip, with the random
+    band starts passed in (negative = band skipped): two frequency bands of 48 bins and two time bands of
+    frames // 8 frames are zeroed."""
+    x = mel_tf.clone()
+    for f0 in freq_starts:
+        if f0 >= 0 and x.shape[1] - freq_width > 0:
+            x[:, f0:f0 + freq_width] = 0
+    tw = x.shape[0] // 8
+    for t0 in time_starts:
+        if t0 >= 0 and x.shape[0] - tw > 0:
+            x[t0:t0 + tw, :] = 0
+    return x
+
+
+def add_noise(waveform, noise, snr_db):
+    """``torchaudio.functional.add_noise`` (torchaudio 2.4.1, absent here: restated from its documented formula -
+    PARITY UNPINNED): scales ``noise`` so that each row of ``waveform`` reaches the requested SNR."""
+    e_sig = torch.linalg.vector_norm(waveform, ord=2, dim=-1) ** 2
+    e_noise = torch.linalg.vector_norm(noise, ord=2, dim=-1) ** 2
+    original_snr_db = 10 * (torch.log10(e_sig) - torch.log10(e_noise))
+    scale = 10 ** ((original_snr_db - snr_db) / 20.0)
+    return waveform + scale.unsqueeze(-1) * noise
+
+
+def torchaudio_melspec_train(wave, freq_starts, time_starts, noise_segments, snr_db, target_len=3000):
+    """``AudioTransform`` training pipeline (transforms.py:122-132), one clip per row, with the random draws
+    given: MelSpectrogram -> SpecAugment on [frames, 80] -> pad/trim to 3000 frames -> AddNoise on the [80, 3000]
+    view (transforms.py:53-59: the mel rows are treated as audio channels) -> whole-clip layer norm."""
+    mag = power_stft(wave)
+    mel = (mag.transpose(1, 2) @ mel_filters_htk()).transpose(1, 2)       # [B,80,frames]
+    out = []
+    for b in range(mel.shape[0]):
+        x = spec_augment(mel[b].t(), freq_starts[b], time_starts[b]).t()  # [80, frames]
+        t = x.shape[-1]
+        x = F.pad(x, (0, target_len - t)) if t < target_len else x[..., :target_len]
+        x = add_noise(x, noise_segments[b].view(1, -1), torch.tensor([float(snr_db[b])]))
+        x = x.t()
+        out.append(F.layer_norm(x, x.shape, eps=1e-8))
+    return torch.stack(out)

@@ -135,3 +135,26 @@ def test_dp_gradient_mean_over_gloo_equals_full_batch():
         p.join(60)
         assert p.exitcode == 0
     assert nb > 1 and worst < 1e-4
+
+
+def test_adaptive_time_mask_draws_like_the_reference():
+    """Host-side draw of AdaptiveTimeMask (datamodule/transforms.py:27-45): one candidate per started 25 frames,
+    mask lengths below the window, nothing outside the clip; a zero first draw skips the mask."""
+    import random
+    from mocov2_whisper_flamingo_amd.transforms import adaptive_time_mask
+
+    class Fixed:
+        def __init__(self, vals):
+            self.vals = list(vals)
+
+        def randrange(self, a, b):
+            v = self.vals.pop(0)
+            assert a <= v < b
+            return v
+
+    # length 75 -> int((75 + 25 - 0.1) // 25) = 3 candidates; pairs (t, len): (4, 6), (0, 9) skipped, (9, 3)
+    z = adaptive_time_mask(75, 10, 25, Fixed([4, 6, 0, 9, 9, 3, 70, 10]))
+    assert [i for i, v in enumerate(z) if v] == [10, 11, 12, 70, 71, 72, 73, 74]
+    for seed in range(20):
+        z = adaptive_time_mask(60, 10, 25, random.Random(seed))
+        assert len(z) == 60 and sum(z) <= 3 * 9

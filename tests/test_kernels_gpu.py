@@ -585,6 +585,75 @@ def test_melspec_layernorm_matches_oracle(dev):
 
 
 @pytest.mark.gpu
+def test_melspec_training_pipeline_matches_oracle(dev):
+    """Training-time pipeline (SpecAugment bands + noise at a target SNR per mel row + clip layer norm) with fixed
+    draws against the CPU restatement.  PARITY UNPINNED like the evaluation variant (torchaudio absent): the
+    add_noise arithmetic follows torchaudio's documented formula.  Covers overlapping / skipped bands, the
+    'clean' SNR level 999999, a 10 s clip (frames // 8 = 125) and a band reaching the trimmed last frame."""
+    import random
+    from mocov2_whisper_flamingo_amd import LogMelFrontend
+    fe = LogMelFrontend("melspec_norm", dev)
+    g = torch.Generator().manual_seed(12)
+    noise_rec = 0.3 * torch.randn(20000, generator=g)
+    for n, fs, ts, off, snr in (
+            (480000, [[0, 31], [10, 20], [-1, 5]], [[0, 2626], [100, 300], [-1, -1]], [0, 17000, 5], [-5.0, 999999.0, 10.0]),
+            (160000, [[3, 3], [31, 0], [7, -1]], [[0, 875], [400, 500], [10, -1]], [100, 200, 300], [0.0, 20.0, 15.0])):
+        wave = _seeded_wave(n, 8, batch=3)
+        wave[2] *= 0.05
+        segs = [noise_rec[o:o + 3000] for o in off]
+        ref = oracle.torchaudio_melspec_train(wave, fs, ts, segs, snr)
+        got = fe.train(wave.to(dev), noise_rec.to(dev), draws=(fs, ts, off, snr))
+        assert got.shape == (3, 3000, 80)
+        err = (got.cpu() - ref).abs().max()
+        assert err < 1e-3 * max(1.0, float(ref.abs().max())), (n, float(err))
+        got16 = fe.train(wave.to(dev), noise_rec.to(dev), draws=(fs, ts, off, snr), dtype=torch.bfloat16, channels_last=False)
+        assert got16.shape == (3, 80, 3000)
+        assert (got16.float().cpu() - ref.transpose(1, 2)).abs().max() < 2e-2 * max(1.0, float(ref.abs().max()))
+    # the host-side draws stay in the reference's ranges
+    fs, ts, off, snr = fe.draw(64, 480000, 20000, random.Random(1))
+    assert all(0 <= f < 32 for r in fs for f in r) and all(0 <= t < 3001 - 375 for r in ts for t in r)
+    assert all(0 <= o <= 17000 for o in off) and set(snr) <= set(map(float, fe.SNR_LEVELS))
+    out = fe.train(_seeded_wave(480000, 9, batch=2).to(dev), noise_rec.to(dev), rng=random.Random(2))
+    assert torch.isfinite(out).all() and abs(float(out[0].mean())) < 1e-3
+    with pytest.raises(ValueError):
+        LogMelFrontend("whisper", dev).train(wave.to(dev), noise_rec.to(dev))
+
+
+@pytest.mark.gpu
+def test_video_transform(dev):
+    """Device VideoTransform against the same steps in core torch (interpolate / flip / normalise): the val path
+    on uint8 and fp32 frames, and the train path (resize 64x64, flip, zeroed frames) with fixed draws."""
+    import random
+    from mocov2_whisper_flamingo_amd import VideoTransform
+    from mocov2_whisper_flamingo_amd.transforms import adaptive_time_mask
+    g = torch.Generator().manual_seed(14)
+    B, T, H, W = 2, 9, 96, 88
+    u8 = torch.randint(0, 256, (B, T, 3, H, W), generator=g, dtype=torch.uint8)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 1, 3, 1, 1)
+    ref = (u8.float() / 255.0 - mean) / std
+    for x in (u8, u8.float()):
+        got = VideoTransform("val")(x.to(dev))
+        assert (got.cpu() - ref).abs().max() < 1e-5
+    assert (VideoTransform("test")(u8[0].to(dev)).cpu() - ref[0]).abs().max() < 1e-5
+    flip = [True, False]
+    zero = [[t in (2, 3, 7) for t in range(T)], [False] * T]
+    x = F.interpolate(u8.float().view(B * T, 3, H, W), size=(64, 64), mode="bilinear", align_corners=False)
+    x = (x / 255.0).view(B, T, 3, 64, 64)
+    x[0] = x[0].flip(-1)
+    x[0, [2, 3, 7]] = 0
+    ref_t = (x - mean) / std
+    got = VideoTransform("train")(u8.float().to(dev), draws=(flip, zero))
+    assert got.shape == (B, T, 3, 64, 64) and (got.cpu() - ref_t).abs().max() < 1e-4
+    z = adaptive_time_mask(75, 10, 25, random.Random(3))
+    assert len(z) == 75 and sum(z) <= 27
+    out = VideoTransform("train")(u8.to(dev), rng=random.Random(4))
+    assert out.shape == (B, T, 3, 64, 64) and torch.isfinite(out).all()
+    with pytest.raises(ValueError):
+        VideoTransform("val")(torch.zeros(2, 4, 8, 8, device=dev))
+
+
+@pytest.mark.gpu
 def test_logmel_rejects_bad_arguments(dev):
     from mocov2_whisper_flamingo_amd._lib import AvsrHipError
     tables = ops.logmel_tables(ops.MEL_WHISPER, dev)

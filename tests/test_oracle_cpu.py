@@ -184,3 +184,24 @@ def test_all_keys_masked_policy():
     zero = oracle.mha_forward(q, kv, in_w, in_b, ow, ob, 1, mask, masked_row="zero")
     assert torch.isnan(nan).all()
     assert torch.allclose(zero, ob.expand(1, 3, 64))
+
+
+def test_add_noise_reaches_the_requested_snr_and_spec_augment_bands():
+    """The restated torchaudio add_noise (unpinned: torchaudio absent) has the property its documentation states:
+    after scaling, 10 log10(E_signal / E_added_noise) equals the requested SNR for every row; an all-zero row
+    gets no noise.  SpecAugment zeroes exactly the drawn bands (transforms.py:144-179)."""
+    from oracle.ref_logmel import add_noise, spec_augment
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(5, 3000, generator=g) * torch.tensor([1.0, 10.0, 0.1, 3.0, 0.0]).view(5, 1)
+    n = torch.randn(1, 3000, generator=g)
+    for snr in (-5.0, 0.0, 20.0):
+        y = add_noise(x, n, torch.tensor([snr]))
+        added = y - x
+        got = 10 * torch.log10((x[:4] ** 2).sum(-1) / (added[:4] ** 2).sum(-1))
+        assert (got - snr).abs().max() < 1e-3
+        assert added[4].abs().max() == 0
+    assert (add_noise(x, n, torch.tensor([999999.0])) - x).abs().max() == 0
+    mel = torch.ones(3001, 80)
+    out = spec_augment(mel, [3, -1], [100, 2626])
+    assert out[:, 3:51].abs().max() == 0 and out[100:475].abs().max() == 0 and out[2626:3001].abs().max() == 0
+    assert out.sum() == (3001 - 750) * (80 - 48)
