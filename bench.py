@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="train: batch-statistics BN + dropout (what the reference's training_step runs); "
                          "eval: running-statistics BN, no dropout")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="issue each batch's frozen encoders inside its own step instead of one step ahead")
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="launch the frozen encoders kernel by kernel instead of replaying their HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -114,14 +118,36 @@ def main():
     B, T = args.batch, 75
     batch = synthetic_batch(B, T, 96, 96, 1234 + rank, dev)
 
-    def step():
-        trainer.zero_grad()
+    def fresh():
         b = dict(batch)
-        b["video_lengths"] = batch["video_lengths"].clone()
-        loss, ctc, ce, _ = model.training_step(b)
+        b["video_lengths"] = batch["video_lengths"].clone()      # forward clamps it in place
+        return b
+
+    def step(b=None, encoded=None):
+        trainer.zero_grad()
+        loss, ctc, ce, _ = model.training_step(b or fresh(), encoded=encoded)
         loss.backward()
         trainer.reduce_gradients()
         trainer.step()
+        return loss
+
+    def run(n):
+        """n complete training steps.  The frozen encoders of batch i+1 are issued (on their own streams) before
+        the trainable tail of batch i, so they run beside its small kernels; every batch's encoders, tail,
+        backward, all-reduce and optimizer step are inside the call, the first batch's encoders un-overlapped."""
+        if not args.pipeline:
+            for _ in range(n):
+                loss = step()
+            return loss
+        cur = fresh()
+        enc = model.encode(model.batch_inputs(cur), ahead=True, graph=args.graph)
+        for i in range(n):
+            nxt = nenc = None
+            if i + 1 < n:
+                nxt = fresh()
+                nenc = model.encode(model.batch_inputs(nxt), ahead=True, graph=args.graph)
+            loss = step(cur, enc)
+            cur, enc = nxt, nenc
         return loss
 
     def barrier():
@@ -130,14 +156,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loss = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    tail = torch.cuda.Stream(device=dev, priority=-1) if args.pipeline else torch.cuda.current_stream()
+    with torch.cuda.stream(tail):               # the dependent chain of small kernels gets the CUs first
+        if args.warmup:
+            run(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        loss = run(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

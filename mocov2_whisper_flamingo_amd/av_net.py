@@ -80,6 +80,8 @@ class AVNet(nn.Module):
         self._seed, self._step = int(seed), 0
         self.overlap_encoders = True        # run the visual frontend on a second stream next to the audio encoder
         self._side = None
+        self._aside = None
+        self._graphs = {}
         self.fusion_module.set_runtime(self._cache, self._dropout_seed)
         if device is not None:
             self.to(device)
@@ -102,37 +104,123 @@ class AVNet(nn.Module):
         return (torch.arange(max_length, device=lengths.device).expand(lengths.size(0), max_length)
                 >= lengths.unsqueeze(1))
 
-    # ---- the shared trunk of forward() and training_step() -----------------
-    def _features(self, inputBatch):
+    # ---- the two frozen encoders ---------------------------------------------
+    @property
+    def _audio_stream(self):
+        dev = torch.cuda.current_device()
+        if self._aside is None or self._aside[0] != dev:
+            self._aside = (dev, torch.cuda.Stream(device=dev))
+        return self._aside[1]
+
+    def encode(self, inputBatch, ahead=False, graph=False):
+        """Runs the frozen Whisper encoder and the frozen visual frontend on ``inputBatch`` (the 5-tuple of
+        ``forward``) and returns an opaque handle that ``forward`` / ``training_step`` accept as ``encoded=``.
+
+        ``graph=True`` replays the encoders from a HIP graph captured on first use for this input shape and
+        module mode (about 250 kernel launches on two streams become one graph launch; the frozen encoders take
+        no per-step scalar arguments, so the recording stays valid while their weights do).
+
+        Nothing in the encoders depends on the trainable weights, so a training loop can issue the encoders of
+        batch i+1 *before* the trainable tail (fusion, head, loss, backward, optimizer) of batch i:
+        ``ahead=True`` puts the audio encoder and the visual frontend on two streams of their own, where they
+        queue behind the previous batch's encoders and run beside the current batch's tail, whose many small
+        kernels leave most of the chip idle."""
         audioBatch, audioMask, videoBatch, videoMask, videoLen = inputBatch
         if not audioBatch.is_cuda:
             raise ops._lib.AvsrHipError("AVNet inputs must be on the GPU: this package has no CPU path")
+        if graph:
+            return self._encode_graph(inputBatch, ahead)
         cdt = self.compute_dtype
-        self._step += 1
         # AUDIO: [B,3000,80] is already channels-last, the layout the conv kernel wants
         channels_last = audioBatch.shape[2] == 80 and audioBatch.shape[1] % 3000 == 0
         frames = audioBatch.shape[1] if channels_last else audioBatch.shape[2]
         windows = frames // 3000 if (self.long_form and frames % 3000 == 0) else 1
-        if windows > 1:                                                     # k x 30 s: k encoder windows per clip
-            if not channels_last:
-                audioBatch, channels_last = ops.transpose2d(audioBatch, dtype=cdt), True
-            audioBatch = audioBatch.contiguous().view(audioBatch.shape[0] * windows, 3000, 80)
         # The two frozen encoders are independent until the fusion: the visual frontend runs on a second HIP
         # stream so its many short kernels fill the CUs the audio encoder's GEMM tails leave idle (and vice versa).
         main = torch.cuda.current_stream()
-        side = self._side_stream if self.overlap_encoders else None
+        side = self._side_stream if (self.overlap_encoders or ahead) else None
+        audio = self._audio_stream if ahead else main
         if side is not None:
             side.wait_stream(main)                                          # the inputs are ready on `main`
             with torch.cuda.stream(side):
                 vis = self.visual_model(videoBatch, videoLen)               # [B,Tv,2048]
-        enc = self.whisper_model.encoder(audioBatch, attention_mask=None, dtype=cdt, channels_last=channels_last)[0]
-        if windows > 1:
-            enc = enc.view(enc.shape[0] // windows, windows * enc.shape[1], enc.shape[2])
-        if side is not None:
-            main.wait_stream(side)
-            vis.record_stream(main)
-        else:
+        if ahead:
+            audio.wait_stream(main)
+        with torch.cuda.stream(audio):
+            if windows > 1:                                                 # k x 30 s: k encoder windows per clip
+                if not channels_last:
+                    audioBatch, channels_last = ops.transpose2d(audioBatch, dtype=cdt), True
+                audioBatch = audioBatch.contiguous().view(audioBatch.shape[0] * windows, 3000, 80)
+            enc = self.whisper_model.encoder(audioBatch, attention_mask=None, dtype=cdt, channels_last=channels_last)[0]
+            if windows > 1:
+                enc = enc.view(enc.shape[0] // windows, windows * enc.shape[1], enc.shape[2])
+        if side is None:
             vis = self.visual_model(videoBatch, videoLen)                   # [B,Tv,2048]
+        done = []
+        if side is not None:
+            done.append((side, side.record_event()))
+        if ahead:
+            done.append((audio, audio.record_event()))
+        return {"enc": enc, "vis": vis, "done": done, "inputs": inputBatch}
+
+    def _encode_graph(self, inputBatch, ahead):
+        audioBatch, _, videoBatch, _, videoLen = inputBatch
+        key = (tuple(audioBatch.shape), audioBatch.dtype, tuple(videoBatch.shape), videoBatch.dtype, self.training,
+               self.visual_model.training, self.compute_dtype, self.long_form, self.whisper_model.encoder.attn_fp8,
+               sum(p._version for p in self.whisper_model.encoder.parameters()),
+               sum(p._version for p in self.visual_model.parameters()), torch.cuda.current_device())
+        main = torch.cuda.current_stream()
+        stream = self._audio_stream
+        rec = self._graphs.get(key)
+        if rec is None:
+            # static inputs; one eager pass first (weight packing, lazily set kernel attributes), then the capture
+            st_in = (torch.empty_like(audioBatch), None, torch.empty_like(videoBatch), None, torch.empty_like(videoLen))
+            stream.wait_stream(main)
+            with torch.cuda.stream(stream):
+                for dst, src in zip(st_in, inputBatch):
+                    if dst is not None:
+                        dst.copy_(src)
+                train_bn = self.visual_model.training
+                running = [b.clone() for b in self.visual_model.buffers()] if train_bn else []
+                self.encode(st_in)
+                stream.synchronize()
+                for b, saved in zip(self.visual_model.buffers(), running):      # the warm-up must not count as a step
+                    b.copy_(saved)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    out = self.encode(st_in)
+                    cur = torch.cuda.current_stream()
+                    for side, ev in out["done"]:                                 # join the visual stream into the capture
+                        cur.wait_event(ev)
+            self._graphs.clear()                                                 # one live recording: its pool is large
+            rec = self._graphs[key] = (g, st_in, out["enc"], out["vis"])
+        g, st_in, enc_s, vis_s = rec
+        stream.wait_stream(main)                                                 # the inputs are ready on `main`
+        with torch.cuda.stream(stream):
+            for dst, src in zip(st_in, inputBatch):
+                if dst is not None:
+                    dst.copy_(src, non_blocking=True)
+            g.replay()
+            enc, vis = enc_s.clone(), vis_s.clone()       # the next replay overwrites the recording's outputs
+            ev = stream.record_event()
+        if not ahead:
+            main.wait_event(ev)
+        return {"enc": enc, "vis": vis, "done": [(stream, ev)], "inputs": inputBatch}
+
+    # ---- the shared trunk of forward() and training_step() -----------------
+    def _features(self, inputBatch, encoded=None):
+        audioBatch, audioMask, videoBatch, videoMask, videoLen = inputBatch
+        self._step += 1
+        if encoded is None:
+            encoded = self.encode(inputBatch)
+        elif encoded["inputs"][0] is not audioBatch or encoded["inputs"][2] is not videoBatch:
+            raise ValueError("`encoded` was computed for a different batch")
+        main = torch.cuda.current_stream()
+        enc, vis = encoded["enc"], encoded["vis"]
+        for stream, ev in encoded["done"]:
+            main.wait_event(ev)
+        for tns in (enc, vis):
+            tns.record_stream(main)
         ready = getattr(self, "_weights_ready", None)     # compute-dtype weight copies rebuilt on another stream
         if ready is not None:
             main.wait_event(ready)
@@ -155,22 +243,28 @@ class AVNet(nn.Module):
         out = Fn.Add3Fn.apply(fused.reshape(B * min_len, d), a.reshape(B * min_len, d), v.reshape(B * min_len, d))
         return out, B, min_len
 
-    def forward(self, inputBatch):
+    def forward(self, inputBatch, encoded=None):
         """inputBatch = (audio [B,3000,80] or [B,80,3000], audio_mask, video [B,T,3,H,W],
-        video_mask, video_len int64 [B]) -> fp32 logits [B, min(1500,T), vocab]."""
-        out, B, T = self._features(inputBatch)
+        video_mask, video_len int64 [B]) -> fp32 logits [B, min(1500,T), vocab].
+        ``encoded``: the handle :meth:`encode` returned for this batch (encoders already issued)."""
+        out, B, T = self._features(inputBatch, encoded)
         lin = self.decoder.linear
         wc, wct = self._cache.get(lin.weight)
         logits = Fn.LinearFn.apply(out, lin.weight, lin.bias, wc, wct, torch.float32, wct.shape[1],
                                    (lin.weight, lin.bias, None, 1))
         return logits.view(B, T, -1)
 
-    def training_step(self, batch, label_smoothing=0.1):
+    @staticmethod
+    def batch_inputs(batch):
+        """The 5-tuple ``forward`` takes, from the data module's batch dict (datamodule/data_module.py:142-152)."""
+        return (batch["audio"], batch["audio_mask"], batch["video"], batch["video_mask"], batch["video_lengths"])
+
+    def training_step(self, batch, label_smoothing=0.1, encoded=None):
         """Counterpart of ``AVSRModule.training_step`` (train.py:143-170): forward,
         CTC + label-smoothed CE with the head, log-softmax and both losses fused.
-        Returns (loss, ctc, ce, logits)."""
-        inp = (batch["audio"], batch["audio_mask"], batch["video"], batch["video_mask"], batch["video_lengths"])
-        out, B, T = self._features(inp)
+        Returns (loss, ctc, ce, logits).  ``encoded``: see :meth:`encode`."""
+        inp = self.batch_inputs(batch)
+        out, B, T = self._features(inp, encoded)
         lin = self.decoder.linear
         wc, wct = self._cache.get(lin.weight)
         ctc, ce, logits = Fn.HeadLossFn.apply(out, lin.weight, lin.bias, wc, wct, batch["target_ids"],

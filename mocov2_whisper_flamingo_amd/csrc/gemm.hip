@@ -8,6 +8,7 @@
 // quad holds 4 consecutive output columns n of one row m: stores, bias and
 // residual reads are 8/16-byte vectors per lane.
 #include "common.h"
+#include <cstdlib>
 
 struct GemmP {
     const void* A; const void* B; void* C;
@@ -348,7 +349,7 @@ template <int BN_, int G_NST, int BM_ = G_BM> constexpr int gemm_lds_bytes() {
 }
 
 template <int BN_, int G_NST, bool CONV, typename OutT, int BM_ = G_BM>
-__global__ __launch_bounds__(256, (G_NST == 1 ? 4 : 2)) void gemm_bf16_kernel(GemmP p) {
+__global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? 4 : 2)) void gemm_bf16_kernel(GemmP p) {
     static_assert(BM_ % 32 == 0 && (BM_ == G_BM || !CONV), "row tile: 4 x whole pieces per wave; conv cursors assume 128");
     constexpr int MI = BM_ / 32;                              // 16-row sub-tiles per wave (two waves stacked in M)
     constexpr int APIECES = BM_ / 8, BPIECES = BN_ / 8;       // 1-KiB pieces (8 rows x 128 B)
@@ -702,6 +703,9 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         };
         if (t96 >= G_NST_SWITCH_TILES && fill(t96, 96, p.M, tn) > 1.12 * fill(t128, 128, p.M, tn)) bm = 96;
     }
+    static const int force_bm = getenv("AVSR_GEMM_BM") ? atoi(getenv("AVSR_GEMM_BM")) : 0;     // experiments only
+    static const int force_nst = getenv("AVSR_GEMM_NST") ? atoi(getenv("AVSR_GEMM_NST")) : 1;
+    if (force_bm == 256 && bf && !conv && !g->col_sum && bn == 128 && g->batch == 1 && p.M >= 4096) bm = 256;
     const int tmS = bf ? bm : FM, tnS = bf ? bn : FN;
     p.tiles_m = (p.M + tmS - 1) / tmS;
     p.tiles_n = (p.N + tnS - 1) / tnS;
@@ -742,7 +746,10 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     } while (0)
     if (bf) {
         const bool single = ntiles * g->batch >= G_NST_SWITCH_TILES;
-        if (bm == 96) {
+        if (bm == 256) {
+            if (force_nst == 2) { if (of) LAUNCHBM(128, 2, float, 256); else LAUNCHBM(128, 2, bf16_t, 256); }
+            else { if (of) LAUNCHBM(128, 1, float, 256); else LAUNCHBM(128, 1, bf16_t, 256); }
+        } else if (bm == 96) {
             if (of) LAUNCHBM(128, 1, float, 96); else LAUNCHBM(128, 1, bf16_t, 96);
         } else if (!conv && bn == 128 && ntiles * g->batch <= G_DEEP_TILES) {     // at most one workgroup per CU: 3 K-steps in flight
             if (of) LAUNCHB(128, 4, false, float); else LAUNCHB(128, 4, false, bf16_t);

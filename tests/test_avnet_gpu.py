@@ -196,6 +196,51 @@ def test_avnet_long_form_chunked_encoder(dev, dtype, attention):
               attention="fp8")
 
 
+@pytest.mark.parametrize("training", [False, True])
+def test_encoders_issued_ahead_and_from_a_graph(dev, training):
+    """The frozen encoders issued one batch ahead on their own streams, eagerly and as a replayed HIP graph, feed
+    the same features to the trainable tail as the in-step call: logits, loss and (train mode) the BN running
+    statistics after two steps are bit-identical, the gradients equal up to summation order, with the second
+    batch different from the first."""
+    import copy
+    m0, _ = _micro_avnet(torch.bfloat16, dev, p_drop=0.0)
+    m0.train(training)
+    batches = [to_device(synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=s), dev) for s in (31, 32)]
+    results = []
+    for mode in ("inline", "ahead", "graph"):
+        m = copy.deepcopy(m0)
+        outs = []
+        fresh = [dict(b, video_lengths=b["video_lengths"].clone()) for b in batches]
+        if mode == "inline":
+            for b in fresh:
+                loss, _, _, logits = m.training_step(b)
+                loss.backward()
+                outs.append((loss.detach().clone(), logits.detach().clone()))
+        else:
+            enc = m.encode(m.batch_inputs(fresh[0]), ahead=True, graph=mode == "graph")
+            for i, b in enumerate(fresh):
+                nxt = m.encode(m.batch_inputs(fresh[i + 1]), ahead=True, graph=mode == "graph") if i + 1 < len(fresh) else None
+                loss, _, _, logits = m.training_step(b, encoded=enc)
+                loss.backward()
+                outs.append((loss.detach().clone(), logits.detach().clone()))
+                enc = nxt
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        stats = {k: v.detach().clone() for k, v in m.visual_model.named_buffers()}
+        results.append((outs, grads, stats))
+    ref_outs, ref_grads, ref_stats = results[0]
+    for outs, grads, stats in results[1:]:
+        for (l, lg), (rl, rlg) in zip(outs, ref_outs):
+            assert torch.equal(l, rl) and torch.equal(lg, rlg)
+        assert grads.keys() == ref_grads.keys()
+        for k in grads:       # fp32 atomics in the LayerNorm / gate gradients: summation order differs run to run
+            assert (grads[k] - ref_grads[k]).abs().max() <= 1e-4 * ref_grads[k].abs().max().clamp_min(1e-6), k
+        assert all(torch.equal(stats[k], ref_stats[k]) for k in stats)
+    with pytest.raises(ValueError):
+        m.training_step(dict(batches[0], video_lengths=batches[0]["video_lengths"].clone()),
+                        encoded=m.encode(m.batch_inputs(batches[1])))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_avnet_forward_and_training_step(dev, dtype):
     m, sd = _micro_avnet(dtype, dev)
