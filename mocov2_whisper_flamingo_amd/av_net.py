@@ -187,7 +187,8 @@ class AVNet(nn.Module):
                 for b, saved in zip(self.visual_model.buffers(), running):      # the warm-up must not count as a step
                     b.copy_(saved)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream):
+                # thread_local: a communicator's watchdog thread may touch the runtime while this thread records
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
                     out = self.encode(st_in)
                     cur = torch.cuda.current_stream()
                     for side, ev in out["done"]:                                 # join the visual stream into the capture
