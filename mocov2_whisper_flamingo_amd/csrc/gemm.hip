@@ -8,7 +8,6 @@
 // quad holds 4 consecutive output columns n of one row m: stores, bias and
 // residual reads are 8/16-byte vectors per lane.
 #include "common.h"
-#include <cstdlib>
 
 struct GemmP {
     const void* A; const void* B; void* C;
@@ -703,9 +702,10 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         };
         if (t96 >= G_NST_SWITCH_TILES && fill(t96, 96, p.M, tn) > 1.12 * fill(t128, 128, p.M, tn)) bm = 96;
     }
-    static const int force_bm = getenv("AVSR_GEMM_BM") ? atoi(getenv("AVSR_GEMM_BM")) : 0;     // experiments only
-    static const int force_nst = getenv("AVSR_GEMM_NST") ? atoi(getenv("AVSR_GEMM_NST")) : 1;
-    if (force_bm == 256 && bf && !conv && !g->col_sum && bn == 128 && g->batch == 1 && p.M >= 4096) bm = 256;
+    // 256-row tiles (a wave owns 128 x 64: a quarter less LDS traffic per MFMA) pay off only where the tile
+    // count stays far above the CU count: +8 % on 4096^3 and larger, a loss on every product of this network.
+    if (bf && !conv && !g->col_sum && bn == 128 && g->batch == 1 && bm == G_BM &&
+        ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 2 * G_NST_SWITCH_TILES && p.K >= 2048) bm = 256;
     const int tmS = bf ? bm : FM, tnS = bf ? bn : FN;
     p.tiles_m = (p.M + tmS - 1) / tmS;
     p.tiles_n = (p.N + tnS - 1) / tnS;
@@ -747,8 +747,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     if (bf) {
         const bool single = ntiles * g->batch >= G_NST_SWITCH_TILES;
         if (bm == 256) {
-            if (force_nst == 2) { if (of) LAUNCHBM(128, 2, float, 256); else LAUNCHBM(128, 2, bf16_t, 256); }
-            else { if (of) LAUNCHBM(128, 1, float, 256); else LAUNCHBM(128, 1, bf16_t, 256); }
+            if (of) LAUNCHBM(128, 1, float, 256); else LAUNCHBM(128, 1, bf16_t, 256);
         } else if (bm == 96) {
             if (of) LAUNCHBM(128, 1, float, 96); else LAUNCHBM(128, 1, bf16_t, 96);
         } else if (!conv && bn == 128 && ntiles * g->batch <= G_DEEP_TILES) {     // at most one workgroup per CU: 3 K-steps in flight

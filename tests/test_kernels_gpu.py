@@ -53,6 +53,21 @@ def test_gemm_row_tile_96(dev, M, N, K, odt):
     assert rel_err(out, ref) < 1e-2
 
 
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+def test_gemm_row_tile_256(dev, odt):
+    """A product large enough for the 256-row tile (>= 1000 such tiles, K >= 2048), ragged in M and N, with bias +
+    residual; checked on a sample of rows (the full fp32 product on the CPU would take minutes)."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 8192 - 37, 4096 - 24, 2048
+    a, b = rnd(g, M, K, dtype=torch.bfloat16), rnd(g, N, K, dtype=torch.bfloat16, scale=0.05)
+    bias, res = torch.randn(N, generator=g), rnd(g, M, N, dtype=odt)
+    out = ops.gemm_nt(a.to(dev, torch.bfloat16), b.to(dev, torch.bfloat16), bias=bias.to(dev), residual=res.to(dev, odt),
+                      out_dtype=odt)
+    rows = torch.cat([torch.arange(0, 300), torch.randint(300, M - 300, (500,), generator=g), torch.arange(M - 300, M)])
+    ref = a[rows] @ b.T + bias + res[rows]
+    assert rel_err(out[rows.to(dev)], ref) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 64), (128, 128, 128), (257, 1001, 512), (75, 2048, 520), (1, 64, 8)])
 def test_gemm_plain(dev, dtype, M, N, K):
