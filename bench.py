@@ -28,7 +28,7 @@ VOCAB = 51865
 PEAK_BF16_TFLOPS = 2500.0                      # dense MFMA peak, MI355X
 
 
-def synthetic_batch(B, T, H, W, seed, dev, L=32):
+def synthetic_batch(B, T, H, W, seed, dev, L=32, mel_frames=3000):
     g = torch.Generator().manual_seed(seed)
     lens = torch.randint(T // 2 + 1, T + 1, (B,), generator=g)
     lens[0] = T
@@ -36,8 +36,8 @@ def synthetic_batch(B, T, H, W, seed, dev, L=32):
     vmask = torch.arange(T).expand(B, T) < lens.unsqueeze(1)
     video = video * vmask[:, :, None, None, None]
     batch = {
-        "audio": torch.randn(B, 3000, 80, generator=g),
-        "audio_mask": torch.ones(B, 3000, dtype=torch.bool),
+        "audio": torch.randn(B, mel_frames, 80, generator=g),
+        "audio_mask": torch.ones(B, mel_frames, dtype=torch.bool),
         "video": video, "video_mask": vmask, "video_lengths": lens,
         "target_ids": torch.randint(1, VOCAB, (B, L), generator=g),
         "target_lengths": torch.full((B, 1), L, dtype=torch.int64),
@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="train: batch-statistics BN + dropout (what the reference's training_step runs); "
                          "eval: running-statistics BN, no dropout")
+    ap.add_argument("--attention", default="bf16", choices=["bf16", "fp8"], help="Whisper self-attention products")
+    ap.add_argument("--seconds", type=int, default=30, choices=[30, 60],
+                    help="clip length: 60 = long-form clips (two encoder windows, 150 video frames)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="issue each batch's frozen encoders inside its own step instead of one step ahead")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
@@ -106,8 +109,9 @@ def main():
     from mocov2_whisper_flamingo_amd.dp import FlatTrainer
 
     torch.manual_seed(1234)        # identical initial weights on every rank
+    windows = args.seconds // 30
     model = AVNet("audiovisual", None, 96, MODELARGS, VOCAB, whisper_config=args.whisper, dtype=torch.bfloat16,
-                  seed=1234 + rank)
+                  seed=1234 + rank, attention=args.attention, long_form=windows > 1)
     with torch.no_grad():          # non-zero gates so the attention / FFN branches carry gradient
         for blk in model.fusion_module.layers:
             blk.attn_gate.fill_(0.5)
@@ -115,8 +119,8 @@ def main():
     model.to(dev)
     model.train(args.mode == "train")
     trainer = FlatTrainer(model, lr=1e-3, bucket_mb=64)
-    B, T = args.batch, 75
-    batch = synthetic_batch(B, T, 96, 96, 1234 + rank, dev)
+    B, T = args.batch, 75 * windows
+    batch = synthetic_batch(B, T, 96, 96, 1234 + rank, dev, mel_frames=3000 * windows)
 
     def fresh():
         b = dict(batch)
@@ -207,11 +211,14 @@ def main():
     if rank == 0:
         clips = B * world * args.steps
         out = {
-            "metric": METRIC, "value": round(clips / dt, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC if (args.whisper, args.seconds) == ("small", 30) else
+            f"AV clips/sec ({args.seconds} s audio+{T} video frames) fwd+bwd, Whisper-{args.whisper}", "value": round(clips / dt, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Whisper-{args.whisper} + MoCo ResNet-50 frontend + gated xattn, batch {B} x 30 s clips "
-                                   f"(75 frames 96x96) per GPU, {args.mode}-mode BN/dropout, fwd+bwd+all-reduce+clip+AdamW",
+            "config": {"workload": f"Whisper-{args.whisper} + MoCo ResNet-50 frontend + gated xattn, batch {B} x {args.seconds} s "
+                                   f"clips ({T} frames 96x96) per GPU, {args.mode}-mode BN/dropout, "
+                                   + ("fp8 encoder attention, " if args.attention == "fp8" else "")
+                                   + "fwd+bwd+all-reduce+clip+AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

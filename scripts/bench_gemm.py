@@ -27,7 +27,9 @@ for name, M, N, K, odt in shapes:
     ld = (N + 7) // 8 * 8
     out = torch.empty(M, ld, device=dev, dtype=odt)[:, :N]
     t = timeit(lambda: ops.gemm_nt(a, b, out=out, bias=bias))
-    print(f"gemm {name:8s} M={M} N={N} K={K} out={str(odt)[6:]:8s} {t*1e6:9.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s")
+    tr = timeit(lambda: ops.gemm_nt(a, b, out=out, bias=bias, residual=out))      # in-place residual update
+    print(f"gemm {name:8s} M={M} N={N} K={K} out={str(odt)[6:]:8s} {t*1e6:9.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s"
+          f" | +residual {tr*1e6:9.1f} us")
 
 convs = [  # (name, n_img, H, C, Cout, k, stride)
     ("l1.c1", 600, 25, 256, 64, 1, 1), ("l1.c2", 600, 25, 64, 64, 3, 1), ("l1.c3", 600, 25, 64, 256, 1, 1),
