@@ -220,12 +220,15 @@ int avsr_avgpool_mask_fwd(avsr_stream_t stream, int in_dtype, int out_dtype, con
 int avsr_video_preprocess(avsr_stream_t stream, int in_is_u8, const void* video, float* out, int64_t B, int64_t T,
                           int64_t H, int64_t W, int64_t OH, int64_t OW, const uint8_t* flip,
                           const uint8_t* frame_zero, const float* mean3, const float* std3);
-/* sum / sumsq: [nparts, C] partial-sum slabs; ws: avsr_bn_finalize_workspace_floats(C) floats,
- * needed when nparts > 32 */
+/* sum / sumsq: [nparts, C] partial-sum slabs; ws: avsr_bn_finalize_workspace_floats(C) floats, needed when
+ * nparts > 8192.  Optional for 512 <= nparts <= 8192: with ws AND tickets (device int32, ceil(C/64) values, all
+ * zero on entry; the kernel leaves them zero) the slab rows are split over up to 16 workgroups per 64 channels
+ * and combined in a fixed order by the last one to finish (same result whichever that is).  Calls that share a
+ * tickets buffer must be ordered on one stream. */
 int64_t avsr_bn_finalize_workspace_floats(int64_t C);
 int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq, int64_t nparts, double count,
                      const float* weight, const float* bias, float* running_mean, float* running_var,
-                     float* scale, float* shift, int64_t C, float eps, float momentum, float* ws);
+                     float* scale, float* shift, int64_t C, float eps, float momentum, float* ws, int32_t* tickets);
 int avsr_bn_fold(avsr_stream_t stream, const float* weight, const float* bias, const float* running_mean,
                  const float* running_var, float* scale, float* shift, int64_t C, float eps);
 /* y = act(x*scale + shift (+ residual)); x may be fp32 while y / residual are bf16 */

@@ -252,38 +252,72 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
     }
 }
 
-// Both steps in one launch for up to a few thousand slab rows: one 1024-thread workgroup per 64 channels,
-// its 16 waves sum interleaved rows (16 loads in flight per lane), fold through LDS in a fixed order
-// (deterministic) and the first wave finalises.  Saves a launch per batch-norm layer.
+// Both steps in one launch for up to a few thousand slab rows.  grid = (ceil(C/64), S): workgroup (g, s) sums
+// slice s of the slab rows for channels 64g..64g+63 - its 16 waves take interleaved rows (16 loads in flight per
+// lane) and fold through LDS in a fixed order.  S = 1: it finalises directly.  S > 1 (thousands of rows: one
+// workgroup per 64 channels would read megabytes alone): it publishes its partial sums in `ws`, takes a ticket,
+// and the workgroup that draws the last ticket adds the S partials in slice order (so the result does not depend
+// on which workgroup that is), finalises and puts the ticket counter back to zero.
 #define BN_FUSED_MAX_PARTS 8192
+#define BN_SPLIT_MAX 16
 __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq,
                                                                   int nparts, float count, const float* __restrict__ weight,
                                                                   const float* __restrict__ bias, float* __restrict__ running_mean,
                                                                   float* __restrict__ running_var, float* __restrict__ scale,
-                                                                  float* __restrict__ shift, int C, float eps, float momentum) {
+                                                                  float* __restrict__ shift, int C, float eps, float momentum,
+                                                                  float* __restrict__ ws, int* __restrict__ tickets) {
     __shared__ float red[2][16][64];
+    __shared__ int last;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int cc = min(c, C - 1);
+    const int S = gridDim.y, slice = blockIdx.y;
+    const int per = (nparts + S - 1) / S, p_end = min(nparts, (slice + 1) * per);
     float a[8], b[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) { a[u] = 0.f; b[u] = 0.f; }
-    int p = w;
-    for (; p + 16 * 7 < nparts; p += 16 * 8) {
+    int p = slice * per + w;
+    for (; p + 16 * 7 < p_end; p += 16 * 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             a[u] += sum[(long)(p + 16 * u) * C + cc];
             b[u] += sumsq[(long)(p + 16 * u) * C + cc];
         }
     }
-    for (; p < nparts; p += 16) { a[0] += sum[(long)p * C + cc]; b[0] += sumsq[(long)p * C + cc]; }
+    for (; p < p_end; p += 16) { a[0] += sum[(long)p * C + cc]; b[0] += sumsq[(long)p * C + cc]; }
     red[0][w][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     red[1][w][lane] = ((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]));
     __syncthreads();
-    if (w != 0 || c >= C) return;
     float s = 0.f, q = 0.f;
+    if (w == 0) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s += red[0][i][lane]; q += red[1][i][lane]; }
+        for (int i = 0; i < 16; ++i) { s += red[0][i][lane]; q += red[1][i][lane]; }
+    }
+    if (S > 1) {
+        if (w == 0 && c < C) {
+            __hip_atomic_store(&ws[((long)slice * 2 + 0) * C + c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws[((long)slice * 2 + 1) * C + c], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // The partial sums are device-scope atomic stores (written through to where every XCD sees them) and are
+        // waited for before the ticket is drawn; the last workgroup reads them with device-scope atomic loads.  A
+        // release / acquire fence pair would order the same thing, but at device scope it writes back and
+        // invalidates this XCD's whole L2 - with the convolution outputs of the layer sitting dirty in it.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            last = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+        __syncthreads();
+        if (!last) return;
+        if (threadIdx.x == 0) __hip_atomic_store(&tickets[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0 && c < C) {
+            s = 0.f; q = 0.f;
+            for (int i = 0; i < S; ++i) {
+                s += __hip_atomic_load(&ws[((long)i * 2 + 0) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q += __hip_atomic_load(&ws[((long)i * 2 + 1) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (w != 0 || c >= C) return;
     const float mean = s / count;
     const float var = fmaxf(q / count - mean * mean, 0.f);
     const float sc = weight[c] * rsqrtf(var + eps);
@@ -336,13 +370,18 @@ extern "C" int64_t avsr_bn_finalize_workspace_floats(int64_t C) { return (int64_
 
 extern "C" int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq, int64_t nparts, double count,
                                 const float* weight, const float* bias, float* running_mean, float* running_var,
-                                float* scale, float* shift, int64_t C, float eps, float momentum, float* ws) {
+                                float* scale, float* shift, int64_t C, float eps, float momentum, float* ws,
+                                int32_t* tickets) {
     if (!sum || !sumsq || !weight || !bias || !scale || !shift || C <= 0 || count <= 0 || nparts <= 0) return AVSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const dim3 fgrid((unsigned)((C + 255) / 256)), fblock(256);
     if (nparts > BN_RED_PARTS && nparts <= BN_FUSED_MAX_PARTS) {
-        hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, s, sum, sumsq, (int)nparts,
-                           (float)count, weight, bias, running_mean, running_var, scale, shift, (int)C, eps, momentum);
+        // thousands of rows: split them over up to 16 workgroups per 64 channels when the caller lends the buffers
+        int S = 1;
+        if (ws && tickets && nparts >= 512) S = (int)std::min<int64_t>(BN_SPLIT_MAX, nparts / 256);
+        hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)S), dim3(1024), 0, s, sum, sumsq,
+                           (int)nparts, (float)count, weight, bias, running_mean, running_var, scale, shift, (int)C, eps,
+                           momentum, ws, tickets);
     } else if (nparts > BN_RED_PARTS) {
         if (!ws) return AVSR_EINVAL;
         hipLaunchKernelGGL(bn_reduce_parts_kernel, dim3((unsigned)((C + 63) / 64), BN_RED_PARTS), dim3(256), 0, s, sum, sumsq,

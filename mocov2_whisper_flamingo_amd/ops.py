@@ -4,6 +4,7 @@ and launches on torch's current stream.  torch only provides device memory and
 the stream.
 """
 import ctypes
+import os
 import torch
 
 from . import _lib
@@ -378,12 +379,20 @@ def bn_finalize(col_sum, col_sumsq, count, weight, bias, running_mean, running_v
     lib = _lib.load()
     C = weight.numel()
     nparts = col_sum.numel() // C
-    ws = None
-    if nparts > 8192:          # beyond the single-launch kernel's range: two-stage reduction needs a workspace
+    ws = tickets = None
+    stream = _stream()
+    if nparts >= 512:          # many slab rows: a workspace lets the reduction spread over several workgroups
         ws = torch.empty(lib.avsr_bn_finalize_workspace_floats(C), dtype=torch.float32, device=weight.device)
-    check(lib.avsr_bn_finalize(_stream(), col_sum.data_ptr(), col_sumsq.data_ptr(), nparts, float(count), weight.data_ptr(),
+        key = (weight.device, stream)
+        tickets = _BN_TICKETS.get(key)
+        if tickets is None or tickets.numel() * 64 < C:      # zero once; every launch leaves them zero
+            tickets = _BN_TICKETS[key] = torch.zeros(max(64, (C + 63) // 64), dtype=torch.int32, device=weight.device)
+    check(lib.avsr_bn_finalize(stream, col_sum.data_ptr(), col_sumsq.data_ptr(), nparts, float(count), weight.data_ptr(),
                                bias.data_ptr(), _p(running_mean), _p(running_var), scale.data_ptr(), shift.data_ptr(),
-                               C, eps, momentum, _p(ws)), "avsr_bn_finalize")
+                               C, eps, momentum, _p(ws), _p(tickets)), "avsr_bn_finalize")
+
+
+_BN_TICKETS = {}     # (device, stream) -> int32 ticket counters of the split batch-norm reduction
 
 
 def bn_fold(weight, bias, running_mean, running_var, eps=1e-5):

@@ -406,7 +406,7 @@ def test_stem_mfma(dev, H, W, train):
     assert rel_err(y, y2) < 2e-2
 
 
-@pytest.mark.parametrize("nparts,C", [(5, 64), (33, 100), (793, 128), (2930, 64), (9000, 256)])
+@pytest.mark.parametrize("nparts,C", [(5, 64), (33, 100), (793, 128), (2930, 64), (2930, 256), (5860, 200), (9000, 256)])
 def test_bn_finalize_slabs(dev, nparts, C):
     """Training-mode BN statistics from [parts, C] partial-sum slabs (direct, single-launch and two-stage paths)."""
     g = torch.Generator().manual_seed(nparts)
@@ -427,6 +427,13 @@ def test_bn_finalize_slabs(dev, nparts, C):
     got = x * sc.cpu() + sh.cpu()
     assert rel_err(got, ref) < 2e-4
     assert rel_err(rmd, bn.running_mean) < 1e-4 and rel_err(rvd, bn.running_var) < 1e-4
+    # the split reduction combines its slices in a fixed order: repeated launches agree to the bit, and the ticket
+    # counters are back at zero for the next one
+    sc2, sh2 = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    for _ in range(3):
+        ops.bn_finalize(s1.to(dev), s2.to(dev), x.shape[0], w.to(dev), b.to(dev), None, None, sc2, sh2)
+        assert torch.equal(sc2, sc) and torch.equal(sh2, sh)
+    assert all(int(t.abs().sum()) == 0 for t in ops._BN_TICKETS.values())
 
 
 @pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
