@@ -163,6 +163,30 @@ class AVNet(nn.Module):
             done.append((audio, audio.record_event()))
         return {"enc": enc, "vis": vis, "done": done, "inputs": inputBatch}
 
+    def _capture_encoders(self, inputBatch, stream, main):
+        """Static input buffers, one eager pass (weight packing, lazily set kernel attributes), then the capture."""
+        audioBatch, _, videoBatch, _, videoLen = inputBatch
+        st_in = (torch.empty_like(audioBatch), None, torch.empty_like(videoBatch), None, torch.empty_like(videoLen))
+        stream.wait_stream(main)
+        with torch.cuda.stream(stream):
+            for dst, src in zip(st_in, inputBatch):
+                if dst is not None:
+                    dst.copy_(src)
+            train_bn = self.visual_model.training
+            running = [b.clone() for b in self.visual_model.buffers()] if train_bn else []
+            self.encode(st_in)
+            stream.synchronize()
+            for b, saved in zip(self.visual_model.buffers(), running):      # the warm-up must not count as a step
+                b.copy_(saved)
+            g = torch.cuda.CUDAGraph()
+            # thread_local: a communicator's watchdog thread may touch the runtime while this thread records
+            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                out = self.encode(st_in)
+                cur = torch.cuda.current_stream()
+                for side, ev in out["done"]:                                 # join the visual stream into the capture
+                    cur.wait_event(ev)
+        return (g, st_in, out["enc"], out["vis"])
+
     def _encode_graph(self, inputBatch, ahead):
         audioBatch, _, videoBatch, _, videoLen = inputBatch
         key = (tuple(audioBatch.shape), audioBatch.dtype, tuple(videoBatch.shape), videoBatch.dtype, self.training,
@@ -173,28 +197,15 @@ class AVNet(nn.Module):
         stream = self._audio_stream
         rec = self._graphs.get(key)
         if rec is None:
-            # static inputs; one eager pass first (weight packing, lazily set kernel attributes), then the capture
-            st_in = (torch.empty_like(audioBatch), None, torch.empty_like(videoBatch), None, torch.empty_like(videoLen))
-            stream.wait_stream(main)
-            with torch.cuda.stream(stream):
-                for dst, src in zip(st_in, inputBatch):
-                    if dst is not None:
-                        dst.copy_(src)
-                train_bn = self.visual_model.training
-                running = [b.clone() for b in self.visual_model.buffers()] if train_bn else []
-                self.encode(st_in)
-                stream.synchronize()
-                for b, saved in zip(self.visual_model.buffers(), running):      # the warm-up must not count as a step
-                    b.copy_(saved)
-                g = torch.cuda.CUDAGraph()
-                # thread_local: a communicator's watchdog thread may touch the runtime while this thread records
-                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                    out = self.encode(st_in)
-                    cur = torch.cuda.current_stream()
-                    for side, ev in out["done"]:                                 # join the visual stream into the capture
-                        cur.wait_event(ev)
+            try:
+                rec = self._capture_encoders(inputBatch, stream, main)
+            except RuntimeError as e:       # e.g. a runtime that refuses the capture: keep working, launch by launch
+                logger.warning("HIP graph capture of the frozen encoders failed (%s); launching them eagerly", e)
+                rec = False
             self._graphs.clear()                                                 # one live recording: its pool is large
-            rec = self._graphs[key] = (g, st_in, out["enc"], out["vis"])
+            self._graphs[key] = rec
+        if rec is False:
+            return self.encode(inputBatch, ahead=ahead)
         g, st_in, enc_s, vis_s = rec
         stream.wait_stream(main)                                                 # the inputs are ready on `main`
         with torch.cuda.stream(stream):

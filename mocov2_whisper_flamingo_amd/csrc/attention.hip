@@ -171,12 +171,20 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
             for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
         }
         const float msc = mrun == -INFINITY ? 0.f : mrun * sc2;
-        float ps = 0.f;
+        // exponent arguments and the row sum two at a time (v_pk_fma_f32 / v_pk_add_f32): the softmax's vector
+        // instructions, not the MFMAs, bound this kernel
+        const f32x2 sc2v = {sc2, sc2}, mscv = {-msc, -msc};
+        f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[st][i], sc2, -msc)); sacc[st][i] = pv; ps += pv; }
-        lsum += ps;                                           // the normaliser is that of the un-dropped softmax
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 arg = __builtin_elementwise_fma((f32x2){sacc[st][i], sacc[st][i + 1]}, sc2v, mscv);
+                const f32x2 pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+                sacc[st][i] = pv[0]; sacc[st][i + 1] = pv[1];
+                ps2 += pv;
+            }
+        lsum += ps2[0] + ps2[1];                              // the normaliser is that of the un-dropped softmax
         if (DROP) {
 #pragma unroll
             for (int st = 0; st < 2; ++st)
