@@ -90,20 +90,32 @@ def main():
                     help="issue each batch's frozen encoders inside its own step instead of one step ahead")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
                     help="launch the frozen encoders kernel by kernel instead of replaying their HIP graph")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="launch each bucket's all-reduce from gradient hooks on a side stream during backward")
+    ap.add_argument("--rehearse-backend", default=None, help="e.g. gloo: rehearse N ranks on fewer GPUs (not a measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("AVSR_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["AVSR_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the measured side")
+    # --rehearse-backend gloo: several ranks share the visible GPU(s) and exchange gradients over gloo - a dry run
+    # of the multi-rank control path on a one-GPU box (its number is not a scaling result)
+    local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_backend:
+            dist.init_process_group(args.rehearse_backend)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from mocov2_whisper_flamingo_amd import AVNet, ops
     from mocov2_whisper_flamingo_amd.dp import FlatTrainer
@@ -118,7 +130,9 @@ def main():
             blk.ff_gate.fill_(0.5)
     model.to(dev)
     model.train(args.mode == "train")
-    trainer = FlatTrainer(model, lr=1e-3, bucket_mb=64)
+    # With the next batch's encoders running beside this batch's tail, the gradient exchange is hidden along with
+    # the rest of the tail: it is issued in stream order after backward (two 64 MB-class buckets), not from hooks.
+    trainer = FlatTrainer(model, lr=1e-3, bucket_mb=64, overlap=args.overlap_allreduce)
     B, T = args.batch, 75 * windows
     batch = synthetic_batch(B, T, 96, 96, 1234 + rank, dev, mel_frames=3000 * windows)
 
@@ -160,8 +174,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    tail = torch.cuda.Stream(device=dev, priority=-1) if args.pipeline else torch.cuda.current_stream()
-    with torch.cuda.stream(tail):               # the dependent chain of small kernels gets the CUs first
+    # the tail gets a stream of its own (the encoders issued ahead must not queue behind it); no stream priorities:
+    # on a GPU shared by two processes a high-priority tail waiting on normal-priority encoder queues stalled for good
+    tail = torch.cuda.Stream(device=dev) if args.pipeline else torch.cuda.current_stream()
+    with torch.cuda.stream(tail):
         if args.warmup:
             run(args.warmup)
         barrier()

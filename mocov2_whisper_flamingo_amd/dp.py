@@ -84,7 +84,7 @@ class FlatTrainer:
             self.buckets.append({"range": (start, total), "params": pending, "left": 0})
         self._bucket_of = {id(p): b for b in self.buckets for p in b["params"]}
         self.overlap = overlap and self.world > 1
-        self.comm_stream = torch.cuda.Stream(device=dev) if (self.on_gpu and self.world > 1) else None
+        self.comm_stream = torch.cuda.Stream(device=dev) if (self.on_gpu and self.overlap) else None
         self._works = []
         # the backward kernels accumulate straight into the flat gradient buffer (functional.grad_sink);
         # gradients that still arrive through autograd keep the ordinary post-accumulate hook
@@ -146,8 +146,24 @@ class FlatTrainer:
         self.join_gradients()
         if self.world == 1:
             return
+        if not self.overlap:
+            # no hooks: every gradient is in place and the current stream has joined the gradient stream, so the
+            # buckets are reduced right here, in stream order (the collective library's own stream does the
+            # work; nothing of this object's runs beside it)
+            staged = self.on_gpu and dist.get_backend(self.group) == "gloo"
+            for b in self.buckets:
+                lo, hi = b["range"]
+                view = self.flat_grad[lo:hi]
+                if staged:      # gloo (CPU rehearsals of the multi-rank path): exchange a host copy
+                    host = view.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                    view.copy_(host)
+                else:
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat_grad.mul_(1.0 / self.world)
+            return
         for b in self.buckets:
-            if not self.overlap or b["left"] > 0:     # unused parameter in the bucket, or no hooks
+            if b["left"] > 0:                         # unused parameter in the bucket
                 self._reduce_bucket(b)
         for w in self._works:
             w.wait()

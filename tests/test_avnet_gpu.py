@@ -492,12 +492,14 @@ def _dp_gpu_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_dp_hooks_and_direct_gradients_two_ranks_one_gpu(dev):
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_dp_hooks_and_direct_gradients_two_ranks_one_gpu(dev, overlap, monkeypatch):
     """Two ranks (gloo, both on this GPU) run the HIP training step on half a batch each with FlatTrainer's
     bucket hooks, gradient stream and communication stream active; the averaged gradients must equal the
     oracle's full-batch gradients.  This is the N > 1 control path the multi-GPU benchmark uses, minus RCCL."""
     import socket
     import torch.multiprocessing as mp
+    monkeypatch.setenv("AVSR_TEST_OVERLAP", overlap)          # "0": buckets reduced in stream order after backward
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
