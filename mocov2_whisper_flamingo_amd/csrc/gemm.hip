@@ -296,6 +296,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][B
 //   NST = 2: double-buffered, 2 workgroups per CU - better when there are too few tiles for that.
 //   NST = 4: grids of at most one workgroup per CU (the small GEMMs of the trainable tail): nothing else hides
 //            the ~1300-cycle DMA latency there, so three K-steps stay in flight (0.55 -> 0.25 us per K-step).
+#ifndef G_FILL_RATIO
+#define G_FILL_RATIO 1.12
+#endif
 #ifndef G_NST_SWITCH_TILES
 #define G_NST_SWITCH_TILES 500
 #endif
@@ -700,7 +703,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
             const long rounds = (t + G_NUM_CU - 1) / G_NUM_CU;
             return (double)M * tnn / ((double)rounds * G_NUM_CU * rows);
         };
-        if (t96 >= G_NST_SWITCH_TILES && fill(t96, 96, p.M, tn) > 1.12 * fill(t128, 128, p.M, tn)) bm = 96;
+        if (t96 >= G_NST_SWITCH_TILES && fill(t96, 96, p.M, tn) > G_FILL_RATIO * fill(t128, 128, p.M, tn)) bm = 96;
     }
     // 256-row tiles (a wave owns 128 x 64: a quarter less LDS traffic per MFMA) pay off only where the tile
     // count stays far above the CU count: +8 % on 4096^3 and larger, a loss on every product of this network.
