@@ -70,7 +70,7 @@ typedef struct {
     const float* scale;   /* [N] or NULL */
     const float* bias;    /* [N] or NULL */
     int32_t act;
-    const void* residual; /* [M,N] (ld = ldr) of out_dtype, or NULL */
+    const void* residual; /* [M,N] (ld = ldr) of out_dtype, or NULL; batch > 1 only as a shared table (res_period > 0) */
     int64_t ldr;
     int64_t res_period;   /* > 0: residual row = m % res_period (a [period,N] table, e.g. positions) */
     const float* gate;    /* device scalar or NULL */
@@ -262,6 +262,11 @@ int avsr_argmax_rows(avsr_stream_t stream, const float* x, int64_t ld, int64_t r
  * Element-wise helpers around the GEMMs.
  * ---------------------------------------------------------------------- */
 int avsr_cast(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y, int64_t n, float scale);
+/* the same for [rows, cols] operands with row strides ldx / ldy >= cols (cols a multiple of 4): a cast into or out of
+ * a padded buffer, e.g. the mel input with one zero frame before and after each clip (the padding=1 of the Whisper
+ * stem convolutions, hf modeling_whisper.py:570-571, made part of the buffer) */
+int avsr_cast_rows(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, int64_t ldx, void* y, int64_t ldy,
+                   int64_t rows, int64_t cols, float scale);
 /* y[b][c][r] = x[b][r][c] * scale; copy (optional, batch 1): copy[r*ldc + c] = x[r][c] * scale in out_dtype */
 int avsr_transpose(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, int64_t ldx, int64_t sx,
                    void* y, int64_t ldy, int64_t sy, int64_t batch, int64_t R, int64_t C, float scale,

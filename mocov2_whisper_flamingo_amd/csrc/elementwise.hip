@@ -16,6 +16,18 @@ __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO*
     }
 }
 
+// y[r][c] = x[r][c] * scale for row-strided operands (cols a multiple of 4): a cast into, or out of, a padded buffer
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const TI* __restrict__ x, long ldx, TO* __restrict__ y, long ldy,
+                                                        long rows, long cols4, float scale) {
+    const long n = rows * cols4, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long r = i / cols4, c = (i - r * cols4) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[r * ldy + c + e] = from_f32<TO>(to_f32<TI>(x[r * ldx + c + e]) * scale);
+    }
+}
+
 // y[b][c][r] = x[b][r][c] * scale  (32x32 LDS tile, padded against bank conflicts); `copy`, when given,
 // also receives the untransposed x * scale in the output type ([R, ldc] rows, batch 1 only): a weight's
 // compute-dtype copy and its transpose in one pass.
@@ -223,6 +235,23 @@ extern "C" int avsr_cast(avsr_stream_t stream, int in_dtype, int out_dtype, cons
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(grid_for(n, 1024, 8192)), block(256);
 #define L(TI, TO) hipLaunchKernelGGL((cast_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, (TO*)y, (long)n, scale)
+    if (in_dtype == AVSR_F32 && out_dtype == AVSR_BF16) L(float, bf16_t);
+    else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_F32) L(bf16_t, float);
+    else if (in_dtype == AVSR_F32 && out_dtype == AVSR_F32) L(float, float);
+    else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_BF16) L(bf16_t, bf16_t);
+    else return AVSR_EINVAL;
+#undef L
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_cast_rows(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, int64_t ldx, void* y,
+                              int64_t ldy, int64_t rows, int64_t cols, float scale) {
+    if (!x || !y || rows <= 0 || cols <= 0 || ldx < cols || ldy < cols) return AVSR_EINVAL;
+    if (cols % 4) return AVSR_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(grid_for(rows * (cols / 4), 256, 8192)), block(256);
+#define L(TI, TO) hipLaunchKernelGGL((cast_rows_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, (long)ldx, (TO*)y, (long)ldy, \
+                                     (long)rows, (long)(cols / 4), scale)
     if (in_dtype == AVSR_F32 && out_dtype == AVSR_BF16) L(float, bf16_t);
     else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_F32) L(bf16_t, float);
     else if (in_dtype == AVSR_F32 && out_dtype == AVSR_F32) L(float, float);

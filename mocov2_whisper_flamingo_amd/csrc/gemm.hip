@@ -691,7 +691,8 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     // vector path: every row start of C (and of the residual) 16-byte aligned
     p.vec_ok = ((g->ldc * osz) % 16 == 0) && aligned_to(g->C, 16) && ((g->strideC * osz) % 16 == 0) &&
                (!g->residual || (((g->ldr * osz) % 16 == 0) && aligned_to(g->residual, 16)));
-    if ((g->residual || g->col_sum) && g->batch > 1) return AVSR_EUNSUPPORTED;
+    // batched launches: a residual only as a table shared by every batch entry (row m % res_period), no statistics
+    if (g->batch > 1 && (g->col_sum || (g->residual && g->res_period <= 0))) return AVSR_EUNSUPPORTED;
     const int bn = (bf && g->N <= 64) ? 64 : 128;
     // Row tile: 128, or 96 where that fills the CUs' last round much better (M = 12000, N = 768: 564 tiles leave a
     // quarter of the chip idle while 52 CUs run a third tile; 750 tiles of 96 rows are 2.93 per CU).

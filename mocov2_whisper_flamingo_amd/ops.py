@@ -464,6 +464,17 @@ def cast(x, dtype, scale=1.0):
     return y
 
 
+def cast_rows(x, out, scale=1.0):
+    """out[r, :] = x[r, :] (dtype conversion) for 2-D views with unit inner stride and any row stride."""
+    lib = _lib.load()
+    _need_cuda(x, out)
+    if x.dim() != 2 or out.shape != x.shape or x.stride(1) != 1 or out.stride(1) != 1:
+        raise ValueError("cast_rows takes two [rows, cols] views with unit inner stride")
+    check(lib.avsr_cast_rows(_stream(), _dt(x), _DT[out.dtype], x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
+                             x.shape[0], x.shape[1], scale), "avsr_cast_rows")
+    return out
+
+
 def transpose2d(x, dtype=None, scale=1.0, pad_to=1, with_copy=False):
     """[..., R, C] (row-major, row stride may exceed C) -> [..., C, Rp] contiguous, Rp = R rounded up
     to a multiple of ``pad_to`` with the padding columns zero (optionally converting dtype).

@@ -154,15 +154,26 @@ class WhisperEncoder(nn.Module):
                 f"Make sure to pad the input mel features to {expected}.")
         pk = self._pack(dtype)
         H, D = cfg.encoder_attention_heads, cfg.d_model
-        if channels_last:
-            xc = x if (x.dtype == dtype and x.is_contiguous()) else ops.cast(x, dtype)
-        else:                                   # [B, C, T] storage: transpose to channels-last on the way
-            xc = ops.transpose2d(input_features, dtype=dtype)
-        h1 = ops.conv_nhwc(xc.view(B, 1, T, C), pk["w1"], 1, 3, 1, (0, 1), bias=pk["b1"], act=ops.ACT_GELU)
+        # The two stem convolutions (kernel 3, padding 1; hf:570-571) as plain GEMMs: with one zero frame stored
+        # before and after each clip, the three taps of output frame t are ONE contiguous run of 3*C values
+        # starting at stored frame t (stride 1) or 2t (stride 2) - an ordinary row-major operand whose row stride
+        # is C (or 2C) and whose rows overlap, batched over the clips.  No per-pixel address arithmetic.
         Tn = cfg.max_source_positions
+        xp = torch.empty((B, T + 2, C), dtype=dtype, device=x.device)
+        xp[:, 0].zero_()
+        xp[:, T + 1].zero_()
+        # [B, C, T] storage (the HF layout) is transposed to channels-last first
+        xc = (x if x.is_contiguous() else x.contiguous()) if channels_last else ops.transpose2d(input_features, dtype=dtype)
+        ops.cast_rows(xc.view(B, T * C), xp.view(B, (T + 2) * C)[:, C:C + T * C])
+        h1p = torch.empty((B, T + 2, D), dtype=dtype, device=x.device)
+        h1p[:, 0].zero_()
+        a1 = torch.as_strided(xp, (B, T, 3 * C), ((T + 2) * C, C, 1))
+        ops.gemm_nt(a1, pk["w1"], bias=pk["b1"], act=ops.ACT_GELU, out=h1p[:, 1:T + 1])
         # gelu(conv2) + positions, written straight into the fp32 residual stream
-        xs = ops.conv_nhwc(h1, pk["w2"], 1, 3, 2, (0, 1), bias=pk["b2"], act=ops.ACT_GELU, residual=pk["pos"],
-                           res_period=Tn, out_dtype=torch.float32).view(B * Tn, D)
+        a2 = torch.as_strided(h1p, (B, Tn, 3 * D), ((T + 2) * D, 2 * D, 1))
+        xs = torch.empty((B, Tn, D), dtype=torch.float32, device=x.device)
+        ops.gemm_nt(a2, pk["w2"], bias=pk["b2"], act=ops.ACT_GELU, residual=pk["pos"], res_period=Tn, out=xs)
+        xs = xs.view(B * Tn, D)
         use_mfma = dtype == torch.bfloat16
         if (self.attn_fp8 if attn_fp8 is None else attn_fp8):
             if not use_mfma:
