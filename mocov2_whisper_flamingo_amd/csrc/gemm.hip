@@ -350,7 +350,11 @@ template <int BN_, int G_NST, int BM_ = G_BM> constexpr int gemm_lds_bytes() {
     return (G_NST * stage > epi ? G_NST * stage : epi) + 2 * BN_ * 4;     // + the tile's scale / bias columns
 }
 
-template <int BN_, int G_NST, bool CONV, typename OutT, int BM_ = G_BM>
+// CONV: 0 = dense operands, 1 = implicit-GEMM convolution with per-lane (tap, channel) cursors (any channel count),
+// 2 = convolution whose channel count is a multiple of the K-step: a K-step lies inside ONE filter tap, so the tap is
+// a scalar, a lane keeps one byte offset per piece (its pixel) and a bit per tap (inside the image or padding), and
+// the K loop carries no per-lane index arithmetic beyond one 64-bit add and the zero-page select.
+template <int BN_, int G_NST, int CONV, typename OutT, int BM_ = G_BM>
 __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? 4 : 2)) void gemm_bf16_kernel(GemmP p) {
     static_assert(BM_ % 32 == 0 && (BM_ == G_BM || !CONV), "row tile: 4 x whole pieces per wave; conv cursors assume 128");
     constexpr int MI = BM_ / 32;                              // 16-row sub-tiles per wave (two waves stacked in M)
@@ -401,16 +405,31 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? 4 : 2)) void gemm_
     unsigned offA[NAL], offB[NBL];
     ConvRow crow[NAL];
     int kh[2] = {0, 0}, kw[2] = {0, 0}, cc[2] = {0, 0};
+    int pixoff[NAL];                        // CONV == 2: byte offset of the lane's pixel (+ swizzled chunk) from A
+    unsigned tapmask[NAL];                  // CONV == 2: bit t set <=> filter tap t of that pixel is inside the image
+    int s_tap = 0, s_kh = 0, s_kw = 0, s_c0 = 0;      // CONV == 2: the (uniform) tap / channel cursor of the next step
 #pragma unroll
     for (int q = 0; q < NAL; ++q) {
         const int r = (NAL * wave + q) * 8 + (lane >> 3);
-        if constexpr (CONV) { crow[q] = conv_row(p, m0 + r); offA[q] = 0; }
+        if constexpr (CONV == 2) {
+            const ConvRow cr = conv_row(p, m0 + r);
+            const int ko = (q & 1) ? kofs[1] : kofs[0];
+            pixoff[q] = ((cr.base + cr.ih0 * p.W + cr.iw0) * p.Cc + ko) * (int)sizeof(bf16_t);
+            unsigned bits = 0;
+            for (int t2 = 0, a = 0; a < p.KH; ++a)
+                for (int b2 = 0; b2 < p.KW; ++b2, ++t2) {
+                    const int ih = cr.ih0 + a, iw = cr.iw0 + b2;
+                    if (cr.ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) bits |= 1u << t2;
+                }
+            tapmask[q] = bits;
+            offA[q] = 0;
+        } else if constexpr (CONV == 1) { crow[q] = conv_row(p, m0 + r); offA[q] = 0; }
         else {
             const int ko = ((NAL * wave + q) & 1) ? kofs[1] : kofs[0];      // swizzle follows the piece's row parity
             offA[q] = (unsigned)(((long)min(r, p.M - 1 - m0) * p.lda + ko) * (long)sizeof(bf16_t));
         }
     }
-    if constexpr (CONV) {
+    if constexpr (CONV == 1) {
         conv_col(p, kofs[0], kh[0], kw[0], cc[0]);
         conv_col(p, kofs[1], kh[1], kw[1], cc[1]);
     }
@@ -429,7 +448,20 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? 4 : 2)) void gemm_
         const int ks = min(kt, nk - 1);
         const bool tail = ktail && ks == nk - 1;                            // workgroup-uniform
         const long kbytes = (long)ks * (G_BK * (long)sizeof(bf16_t));
-        if constexpr (CONV) {
+        if constexpr (CONV == 2) {
+            const char* tb = (const char*)A + ((long)(s_kh * p.W + s_kw) * p.Cc + s_c0) * (long)sizeof(bf16_t);
+#pragma unroll
+            for (int q = 0; q < NAL; ++q) {
+                const uintptr_t real = (uintptr_t)(tb + (long)pixoff[q]);
+                const uintptr_t a = zaddr + ((real - zaddr) & (uintptr_t)(-(long)((tapmask[q] >> s_tap) & 1u)));
+                __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (NAL * wave + q) * 1024), 16, 0, 0);
+            }
+            if (kt < nk - 1) {              // the next step: 64 channels further, or the next tap
+                s_c0 += G_BK;
+                if (s_c0 >= p.Cc) { s_c0 = 0; ++s_tap; if (++s_kw == p.KW) { s_kw = 0; ++s_kh; } }
+            }
+        }
+        if constexpr (CONV == 1) {
             uintptr_t kin[2] = {~(uintptr_t)0, ~(uintptr_t)0};
             if (ktail) {
                 kin[0] = (uintptr_t)(-(long)(kt * G_BK + kofs[0] < p.K));
@@ -537,14 +569,14 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? 4 : 2)) void gemm_
         wait_vmcnt<0>();                        // drain the re-loaded steps before the LDS is reused
     }
     STAMP(3);
-    epilogue_tile<BN_, OutT, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+    epilogue_tile<BN_, OutT, CONV != 0, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
 #ifdef GEMM_STAMPS
     STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(5);
 #ifdef GEMM_STAMPS_TWICE
     __syncthreads();
-    epilogue_tile<BN_, OutT, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+    epilogue_tile<BN_, OutT, CONV != 0, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
     STAMP(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(7);
@@ -735,7 +767,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     do {                                                                                                       \
         static bool attr_set = false;                                                                          \
         constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV, BMV>();                                            \
-        auto kfn = gemm_bf16_kernel<BNV, NSTV, false, OT, BMV>;                                                \
+        auto kfn = gemm_bf16_kernel<BNV, NSTV, 0, OT, BMV>;                                                \
         if (!attr_set) {                                                                                       \
             if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)   \
                 != hipSuccess) return AVSR_EHIP;                                                               \
@@ -745,9 +777,15 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     } while (0)
 #define LAUNCH_CV_OT(BNV, NSTV)                                                                                \
     do {                                                                                                       \
-        if (conv) { if (of) LAUNCHB(BNV, NSTV, true, float); else LAUNCHB(BNV, NSTV, true, bf16_t); }          \
-        else      { if (of) LAUNCHB(BNV, NSTV, false, float); else LAUNCHB(BNV, NSTV, false, bf16_t); }        \
+        if (conv) { if (of) LAUNCHB(BNV, NSTV, 1, float); else LAUNCHB(BNV, NSTV, 1, bf16_t); }                \
+        else      { if (of) LAUNCHB(BNV, NSTV, 0, float); else LAUNCHB(BNV, NSTV, 0, bf16_t); }                \
     } while (0)
+#define LAUNCH_FAST_OT(BNV, NSTV) do { if (of) LAUNCHB(BNV, NSTV, 2, float); else LAUNCHB(BNV, NSTV, 2, bf16_t); } while (0)
+    // whole K-steps inside one filter tap, taps in one 32-bit mask, pixel byte offsets in 31 bits.  Used with the
+    // double-buffered instantiations only (grids below the single-stage switch): under the 128-register cap of the
+    // single-stage ones its extra per-lane state spills inside the K loop (measured: half the rate).
+    const bool conv_fast = bf && conv && g->conv.C % G_BK == 0 && g->conv.KH * g->conv.KW <= 32 &&
+                           (g->M / ((int64_t)g->conv.OH * g->conv.OW)) * g->conv.H * g->conv.W * g->conv.C * 2 < (1ll << 31);
     if (bf) {
         const bool single = ntiles * g->batch >= G_NST_SWITCH_TILES;
         if (bm == 256) {
@@ -755,9 +793,9 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         } else if (bm == 96) {
             if (of) LAUNCHBM(128, 1, float, 96); else LAUNCHBM(128, 1, bf16_t, 96);
         } else if (!conv && bn == 128 && ntiles * g->batch <= G_DEEP_TILES) {     // at most one workgroup per CU: 3 K-steps in flight
-            if (of) LAUNCHB(128, 4, false, float); else LAUNCHB(128, 4, false, bf16_t);
-        } else if (bn == 64) { if (single) LAUNCH_CV_OT(64, 1); else LAUNCH_CV_OT(64, 2); }
-        else          { if (single) LAUNCH_CV_OT(128, 1); else LAUNCH_CV_OT(128, 2); }
+            if (of) LAUNCHB(128, 4, 0, float); else LAUNCHB(128, 4, 0, bf16_t);
+        } else if (bn == 64) { if (single) LAUNCH_CV_OT(64, 1); else if (conv_fast) LAUNCH_FAST_OT(64, 2); else LAUNCH_CV_OT(64, 2); }
+        else          { if (single) LAUNCH_CV_OT(128, 1); else if (conv_fast) LAUNCH_FAST_OT(128, 2); else LAUNCH_CV_OT(128, 2); }
     } else {
         if (conv) { if (of) LAUNCH(gemm_f32_kernel, true, float); else LAUNCH(gemm_f32_kernel, true, bf16_t); }
         else      { if (of) LAUNCH(gemm_f32_kernel, false, float); else LAUNCH(gemm_f32_kernel, false, bf16_t); }
@@ -766,5 +804,6 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
 #undef LAUNCHB
 #undef LAUNCHBM
 #undef LAUNCH_CV_OT
+#undef LAUNCH_FAST_OT
     return avsr_launch_status();
 }
