@@ -303,6 +303,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][B
 #define G_NST_SWITCH_TILES 500
 #endif
 #define G_NUM_CU 256
+#ifndef G_SMALL_TILES
+#define G_SMALL_TILES 128
+#endif
 #ifndef G_DEEP_TILES
 #define G_DEEP_TILES 256
 #endif
@@ -725,10 +728,16 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
                (!g->residual || (((g->ldr * osz) % 16 == 0) && aligned_to(g->residual, 16)));
     // batched launches: a residual only as a table shared by every batch entry (row m % res_period), no statistics
     if (g->batch > 1 && (g->col_sum || (g->residual && g->res_period <= 0))) return AVSR_EUNSUPPORTED;
-    const int bn = (bf && g->N <= 64) ? 64 : 128;
+    int bn = (bf && g->N <= 64) ? 64 : 128;
+    // A grid of a few dozen 128 x 128 tiles leaves most CUs idle while each busy one grinds through its tile's whole
+    // K loop at one CU's MFMA rate: 64 x 64 tiles put four times as many CUs to work on a quarter of the tile each.
+    const bool small = bf && !conv && !g->col_sum && g->batch == 1 && bn == 128 &&
+                       ((g->M + 127) / 128) * ((g->N + 127) / 128) <= G_SMALL_TILES;
+    if (small) bn = 64;
     // Row tile: 128, or 96 where that fills the CUs' last round much better (M = 12000, N = 768: 564 tiles leave a
     // quarter of the chip idle while 52 CUs run a third tile; 750 tiles of 96 rows are 2.93 per CU).
     int bm = G_BM;
+    if (small) bm = 64;
     if (bf && !conv && !g->col_sum && bn == 128 && g->batch == 1) {
         const long tn = (p.N + 127) / 128;
         const long t128 = ((p.M + 127) / 128) * tn, t96 = ((p.M + 95) / 96) * tn;
@@ -788,7 +797,9 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
                            (g->M / ((int64_t)g->conv.OH * g->conv.OW)) * g->conv.H * g->conv.W * g->conv.C * 2 < (1ll << 31);
     if (bf) {
         const bool single = ntiles * g->batch >= G_NST_SWITCH_TILES;
-        if (bm == 256) {
+        if (small) {
+            if (of) LAUNCHBM(64, 4, float, 64); else LAUNCHBM(64, 4, bf16_t, 64);
+        } else if (bm == 256) {
             if (of) LAUNCHBM(128, 1, float, 256); else LAUNCHBM(128, 1, bf16_t, 256);
         } else if (bm == 96) {
             if (of) LAUNCHBM(128, 1, float, 96); else LAUNCHBM(128, 1, bf16_t, 96);

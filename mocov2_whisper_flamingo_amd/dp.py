@@ -110,6 +110,15 @@ class FlatTrainer:
     def _reduce_bucket(self, b):
         lo, hi = b["range"]
         view = self.flat_grad[lo:hi]
+        if self.on_gpu and dist.get_backend(self.group) == "gloo":
+            # gloo (rehearsals of the multi-rank path on one GPU): exchange a host copy, synchronously - its
+            # CUDA-tensor path stalled after a few large all-reduces on this stack
+            if self.grad_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.grad_stream)
+            host = view.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            view.copy_(host)
+            return
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             if self.grad_stream is not None:

@@ -33,7 +33,8 @@ for name, M, N, K, odt in [("qkv", 12000, 2304, 768, torch.bfloat16), ("out", 12
                            ("fc1", 12000, 3072, 768, torch.bfloat16), ("fc2", 12000, 768, 3072, torch.float32),
                            ("4096^3", 4096, 4096, 4096, torch.bfloat16), ("tiny", 128, 128, 64, torch.bfloat16),
                            ("t512", 600, 512, 512, torch.bfloat16), ("t2048", 600, 512, 2048, torch.float32),
-                           ("dW", 512, 2048, 600, torch.float32)]:
+                           ("dW", 512, 2048, 600, torch.float32), ("t80", 600, 2048, 512, torch.bfloat16),
+                           ("t128", 1024, 2048, 512, torch.bfloat16), ("t192", 1500, 2048, 512, torch.bfloat16)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16); b = torch.randn(N, K, device=dev).to(torch.bfloat16)
     out = torch.empty(M, N, device=dev, dtype=odt)
     cases.append((name, desc(a, b, out), 2.0 * M * N * K, (a, b, out)))
