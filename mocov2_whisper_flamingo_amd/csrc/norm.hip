@@ -366,6 +366,39 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* __restrict__ x,
     }
 }
 
+// bf16 -> bf16 form for channel counts that are a multiple of 8 with 16-byte-aligned operands: 8 channels per
+// thread as one 16-byte load / store.  A thread's channel group is fixed when the grid stride is a multiple of
+// C/8 (the host rounds it), so scale and shift live in registers for the whole kernel and the loop is load,
+// 8 fma, (add, max), store: two independent 16-byte loads in flight per thread and iteration.
+__global__ __launch_bounds__(256) void bn_apply_bf16x8_kernel(const bf16_t* x, const bf16_t* res,   // y may be x
+                                                              bf16_t* y, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, long n8, int C8, int relu) {
+    const long stride = (long)gridDim.x * blockDim.x;          // multiple of C8
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(i % C8) * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[c + e]; sh[e] = shift[c + e]; }
+    for (; i < n8; i += 2 * stride) {
+        const long j = i + stride;
+        const bool two = j < n8;
+        const bf16x8 a0 = *(const bf16x8*)(x + i * 8);
+        const bf16x8 a1 = two ? *(const bf16x8*)(x + j * 8) : a0;
+        bf16x8 r0 = a0, r1 = a0;
+        if (res) { r0 = *(const bf16x8*)(res + i * 8); if (two) r1 = *(const bf16x8*)(res + j * 8); }
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v0 = fmaf((float)a0[e], sc[e], sh[e]), v1 = fmaf((float)a1[e], sc[e], sh[e]);
+            if (res) { v0 += (float)r0[e]; v1 += (float)r1[e]; }
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            o0[e] = (bf16_t)v0; o1[e] = (bf16_t)v1;
+        }
+        *(bf16x8*)(y + i * 8) = o0;
+        if (two) *(bf16x8*)(y + j * 8) = o1;
+    }
+}
+
 extern "C" int64_t avsr_bn_finalize_workspace_floats(int64_t C) { return (int64_t)BN_RED_PARTS * 2 * C; }
 
 extern "C" int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq, int64_t nparts, double count,
@@ -407,10 +440,26 @@ extern "C" int avsr_bn_apply(avsr_stream_t stream, int in_dtype, int out_dtype, 
                              void* y, const float* scale, const float* shift, int64_t rows, int64_t C, int relu) {
     if (!x || !y || !scale || !shift || rows <= 0 || C <= 0) return AVSR_EINVAL;
     if (C % 4) return AVSR_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == AVSR_BF16 && out_dtype == AVSR_BF16 && C % 8 == 0 && (2048 % (C / 8) == 0 || (C / 8) % 256 == 0) &&
+        (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) % 16) == 0) {
+        const long n8 = rows * C / 8;
+        const int C8 = (int)(C / 8);
+        // grid stride = 256 * blocks must be a multiple of C8: blocks a multiple of C8 / gcd(C8, 256)
+        long unit = 1;
+        if (C8 > 256) unit = C8 / 256;                          // C8 is then a multiple of 256
+        long blocks = std::min<long>((n8 + 511) / 512, 2048);
+        blocks = std::max<long>(unit, blocks / unit * unit);
+        if (C8 <= 256 && 256 % C8 != 0) blocks = 0;             // not reached: the test above admits powers of two only
+        if (blocks > 0) {
+            hipLaunchKernelGGL(bn_apply_bf16x8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x,
+                               (const bf16_t*)residual, (bf16_t*)y, scale, shift, n8, C8, relu);
+            return avsr_launch_status();
+        }
+    }
     const long n4 = rows * C / 4;
     long nb = (n4 + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipStream_t s = (hipStream_t)stream;
 #define L(TI, TO) hipLaunchKernelGGL((bn_apply_kernel<TI, TO>), dim3((unsigned)nb), dim3(256), 0, s, (const TI*)x, \
                                      (const TO*)residual, (TO*)y, scale, shift, n4, (int)C, relu)
     if (in_dtype == AVSR_F32 && out_dtype == AVSR_F32) L(float, float);
