@@ -347,6 +347,46 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
     }
 }
 
+// bf16 form, 8 channels (one 16-byte load) per thread and tap; 32-bit index arithmetic.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bf16x8_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  int N, int H, int W, int C8, int OH, int OW) {
+    const int total = N * OH * OW * C8;                     // host guarantees < 2^31
+    const int stride = gridDim.x * blockDim.x;              // multiple of C8: a thread keeps its channel group
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = i % C8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale ? scale[c8 * 8 + e] : 1.f; sh[e] = scale ? shift[c8 * 8 + e] : 0.f; }
+    for (; i < total; i += stride) {
+        int pp = i / C8;
+        const int ow = pp % OW; pp /= OW;
+        const int oh = pp % OH;
+        const int n = pp / OH;
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+                if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+                const bf16x8 v8 = *(const bf16x8*)(x + ((long)((n * H + ih) * W + iw) * C8 + c8) * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = (float)v8[e];
+                    if (scale) v = fmaxf(fmaf(v, sc[e], sh[e]), 0.f);
+                    m[e] = fmaxf(m[e], v);
+                }
+            }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)m[e];
+        *(bf16x8*)(y + ((long)((n * OH + oh) * OW + ow) * C8 + c8) * 8) = o;
+    }
+}
+
 // Global average pool over HW pixels of an NHWC tensor [B*T, HW, C] -> [B*T, C];
 // frames t >= len[b] are written as zeros (moco_visual_frontend.py:42,49).
 // VideoTransform of the data path (datamodule/transforms.py:61-96) for frames already on the GPU: optional bilinear
@@ -478,9 +518,17 @@ extern "C" int avsr_maxpool3x3s2(avsr_stream_t stream, int in_dtype, int out_dty
     if ((scale == nullptr) != (shift == nullptr)) return AVSR_EINVAL;
     const int OH = (int)((H + 2 - 3) / 2 + 1), OW = (int)((W + 2 - 3) / 2 + 1);
     const long total = N * OH * OW * (C / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == AVSR_BF16 && out_dtype == AVSR_BF16 && C % 8 == 0 && 256 % (C / 8) == 0 &&
+        (((uintptr_t)x | (uintptr_t)y) % 16) == 0 && (long)N * H * W * (C / 8) < (1l << 31)) {
+        const long t8 = (long)N * OH * OW * (C / 8);
+        const long nb8 = std::min<long>((t8 + 255) / 256, 16384);
+        hipLaunchKernelGGL(maxpool3x3s2_bf16x8_kernel, dim3((unsigned)nb8), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, scale,
+                           shift, (int)N, (int)H, (int)W, (int)(C / 8), OH, OW);
+        return avsr_launch_status();
+    }
     long nb = (total + 255) / 256;
     if (nb > 8192) nb = 8192;
-    hipStream_t s = (hipStream_t)stream;
 #define L(TI, TO) hipLaunchKernelGGL((maxpool3x3s2_kernel<TI, TO>), dim3((unsigned)nb), dim3(256), 0, s, (const TI*)x, (TO*)y, \
                                      scale, shift, (int)N, (int)H, (int)W, (int)C, OH, OW)
     if (in_dtype == AVSR_F32 && out_dtype == AVSR_F32) L(float, float);
