@@ -25,6 +25,8 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
     *(bf16x4*)p = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
 }
 
+// One wave per PAIR of rows: both rows' loads are issued before the first reduction, so a wave has twice the bytes
+// in flight while it waits (the kernel is a stream of 3 KB rows: bandwidth comes from loads in flight).
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict__ x, long ldx, TO* __restrict__ y, long ldy,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -32,44 +34,53 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const TI* xr = x + (long)row * ldx;
-    float v[LN_MAXV][4];
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= rows) return;
+    const int nr = min(2, rows - row0);
+    float v[2][LN_MAXV][4];
     const int nch = D >> 2;   // chunks of 4
-    float s = 0.f;
+    float s[2] = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) { load4<TI>(xr + c * 4, v[i]); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
-    }
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
+    for (int r = 0; r < 2; ++r) {
+        const TI* xr = x + (long)(row0 + (r < nr ? r : 0)) * ldx;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) { load4<TI>(xr + c * 4, v[r][i]); s[r] += v[r][i][0] + v[r][i][1] + v[r][i][2] + v[r][i][3]; }
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-    if (lane == 0) { if (mean_out) mean_out[row] = mean; if (rstd_out) rstd_out[row] = rstd; }
-    TO* yr = y + (long)row * ldy;
-    const float* ar = add ? add + (long)(row % add_period) * D : nullptr;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
-            float g[4], b[4], o[4];
-            load4<float>(gamma + c * 4, g);
-            load4<float>(beta + c * 4, b);
+    for (int r = 0; r < 2; ++r) {
+        if (r >= nr) break;
+        const int row = row0 + r;
+        const float mean = wave_sum(s[r]) / (float)D;
+        float q = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-            if (ar) { float a[4]; load4<float>(ar + c * 4, a);
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += a[e]; }
-            store4<TO>(yr + c * 4, o);
+                for (int e = 0; e < 4; ++e) { const float d = v[r][i][e] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+        if (lane == 0) { if (mean_out) mean_out[row] = mean; if (rstd_out) rstd_out[row] = rstd; }
+        TO* yr = y + (long)row * ldy;
+        const float* ar = add ? add + (long)(row % add_period) * D : nullptr;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                float g[4], b[4], o[4];
+                load4<float>(gamma + c * 4, g);
+                load4<float>(beta + c * 4, b);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[r][i][e] - mean) * rstd * g[e] + b[e];
+                if (ar) { float a[4]; load4<float>(ar + c * 4, a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += a[e]; }
+                store4<TO>(yr + c * 4, o);
+            }
         }
     }
 }
@@ -167,7 +178,7 @@ extern "C" int avsr_layernorm_fwd(avsr_stream_t stream, int in_dtype, int out_dt
     if (!x || !y || !gamma || !beta || rows <= 0) return AVSR_EINVAL;
     if (D % 4 || D > 64 * 4 * LN_MAXV || ldx % 4 || ldy % 4) return AVSR_EUNSUPPORTED;
     if (add && add_period <= 0) return AVSR_EINVAL;
-    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    dim3 grid((unsigned)((rows + 7) / 8)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define L(TI, TO) hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, (long)ldx, (TO*)y, \
                                      (long)ldy, gamma, beta, add, (int)add_period, mean, rstd, (int)rows, (int)D, eps)
