@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libavsr_hip.so")
+LIB_PATH = os.environ.get("AVSR_HIP_LIB") or os.path.join(_HERE, "libavsr_hip.so")      # override: A/B builds of the library
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_RELU_AFTER_RESIDUAL = 0, 1, 2, 3

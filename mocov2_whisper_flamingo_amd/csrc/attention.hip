@@ -55,7 +55,13 @@ __device__ __forceinline__ uint64_t dead_keys(const uint8_t* mb, int kv0, int Tk
 }
 
 template <bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
+#ifndef ATT_OCC
+#define ATT_OCC 3
+#endif
+#ifndef ATT_UNROLL
+#define ATT_UNROLL 1
+#endif
+__global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
                                                             long ldk, const bf16_t* __restrict__ V, long ldv,
                                                             bf16_t* __restrict__ O, long ldo, const uint8_t* __restrict__ mask,
                                                             float* __restrict__ lse, int Tq, int Tk, int H, float scale,
@@ -126,87 +132,74 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
         const bool more = kv0 + 64 < kend;
         if (more) prefetch(kv0 + 64);                         // lands in registers while this tile is computed
 
-        f32x16 sacc[2];
-#pragma unroll
+        // 32 keys at a time (rolled): half the score registers and a quarter of the K / V fragments are live at
+        // once, which is what lets four waves share a SIMD (the 64-key form needed ~250 VGPRs: two waves).
+#pragma unroll ATT_UNROLL
         for (int st = 0; st < 2; ++st) {
+            f32x16 sacc;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[st][i] = 0.f;
+            for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)&Ks[k_off(32 * st + r, 2 * ks + hf)];
-                sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[st], 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
             }
-        }
-        // sacc[st][reg] = S[q][key = kv0 + 32 st + (reg&3) + 8 (reg>>2) + 4 hf]   (raw, unscaled)
-        if (mb || kv0 + 64 > Tk) {                            // block-uniform: only masked / tail tiles pay for this
-            const uint64_t dead = dead_keys(mb, kv0, Tk, lane);
-            if (dead) {
-#pragma unroll
-                for (int st = 0; st < 2; ++st)
+            // sacc[reg] = S[q][key = kv0 + 32 st + (reg&3) + 8 (reg>>2) + 4 hf]   (raw, unscaled)
+            if (mb || kv0 + 64 > Tk) {                        // block-uniform: only masked / tail tiles pay for this
+                const uint32_t dead = (uint32_t)(dead_keys(mb, kv0, Tk, lane) >> (32 * st));
+                if (dead) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
-                        if ((dead >> (32 * st + (i & 3) + 8 * (i >> 2) + 4 * hf)) & 1) sacc[st][i] = -INFINITY;
+                        if ((dead >> ((i & 3) + 8 * (i >> 2) + 4 * hf)) & 1) sacc[i] = -INFINITY;
+                }
             }
-        }
-        if (causal && kv0 + 63 > qt * 128 + coff) {          // block-uniform: only tiles that touch the diagonal
-            const int last = q + coff - kv0;                  // last visible key of this lane's row, tile-relative
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
+            if (causal && kv0 + 63 > qt * 128 + coff) {      // block-uniform: only tiles that touch the diagonal
+                const int last = q + coff - kv0 - 32 * st;    // last visible key of this lane's row, sub-tile-relative
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if (32 * st + (i & 3) + 8 * (i >> 2) + 4 * hf > last) sacc[st][i] = -INFINITY;
-        }
-        float mx = sacc[0][0];
+                    if ((i & 3) + 8 * (i >> 2) + 4 * hf > last) sacc[i] = -INFINITY;
+            }
+            float mx = sacc[0];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[0][i]);
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (__any(mx > mrun)) {                           // some row's maximum moved: rescale what is accumulated
+                const float mnew = fmaxf(mrun, mx);
+                const float alpha = mnew > mrun ? exp2f((mrun - mnew) * sc2) : 1.0f;
+                mrun = mnew;
+                lsum *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[1][i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (__any(mx > mrun)) {                               // some row's maximum moved: rescale what is accumulated
-            const float mnew = fmaxf(mrun, mx);
-            const float alpha = mnew > mrun ? exp2f((mrun - mnew) * sc2) : 1.0f;
-            mrun = mnew;
-            lsum *= alpha;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
-        }
-        const float msc = mrun == -INFINITY ? 0.f : mrun * sc2;
-        // exponent arguments and the row sum two at a time (v_pk_fma_f32 / v_pk_add_f32): the softmax's vector
-        // instructions, not the MFMAs, bound this kernel
-        const f32x2 sc2v = {sc2, sc2}, mscv = {-msc, -msc};
-        f32x2 ps2 = {0.f, 0.f};
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
+                for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+            }
+            const float msc = mrun == -INFINITY ? 0.f : mrun * sc2;
+            const f32x2 sc2v = {sc2, sc2}, mscv = {-msc, -msc};
+            f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
-                const f32x2 arg = __builtin_elementwise_fma((f32x2){sacc[st][i], sacc[st][i + 1]}, sc2v, mscv);
+                const f32x2 arg = __builtin_elementwise_fma((f32x2){sacc[i], sacc[i + 1]}, sc2v, mscv);
                 const f32x2 pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
-                sacc[st][i] = pv[0]; sacc[st][i + 1] = pv[1];
+                sacc[i] = pv[0]; sacc[i + 1] = pv[1];
                 ps2 += pv;
             }
-        lsum += ps2[0] + ps2[1];                              // the normaliser is that of the un-dropped softmax
-        if (DROP) {
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
+            lsum += ps2[0] + ps2[1];                          // the normaliser is that of the un-dropped softmax
+            if (DROP) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint32_t bits[4];
                     avsr_philox4(seed, avsr_attn_counter(row, tk4, kv0 + 32 * st + 8 * g + 4 * hf), bits);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        sacc[st][4 * g + e] = avsr_bits_keep(bits[e], pdrop) ? sacc[st][4 * g + e] * keep_scale : 0.f;
+                        sacc[4 * g + e] = avsr_bits_keep(bits[e], pdrop) ? sacc[4 * g + e] * keep_scale : 0.f;
                 }
-        }
-
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pf = acc_to_bf16(sacc[st], s2);
+                const bf16x8 pf = acc_to_bf16(sacc, s2);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr_frag(Vs, st, s2, db, lane), pf, oacc[db], 0, 0, 0);
             }
+        }
         if (more) stage(cur ^ 1);                             // the other buffer was last read one barrier ago
         __syncthreads();
     }
@@ -931,4 +924,14 @@ extern "C" int avsr_attn_bwd(avsr_stream_t stream, int dtype, int use_mfma, cons
     else return AVSR_EINVAL;
 #undef RUN
     return avsr_launch_status();
+}
+
+// Debugging aid: resident workgroups per CU the runtime computes for the forward kernels (registers + LDS).
+extern "C" int avsr_debug_attn_occupancy(int which) {
+    int n = -1;
+    hipError_t e = hipSuccess;
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<false>, 256, 0);
+    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<true>, 256, 0);
+    else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_fp8_kernel, 256, 0);
+    return e == hipSuccess ? n : -1;
 }
