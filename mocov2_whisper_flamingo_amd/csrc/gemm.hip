@@ -296,11 +296,14 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][B
 //   NST = 2: double-buffered, 2 workgroups per CU - better when there are too few tiles for that.
 //   NST = 4: grids of at most one workgroup per CU (the small GEMMs of the trainable tail): nothing else hides
 //            the ~1300-cycle DMA latency there, so three K-steps stay in flight (0.55 -> 0.25 us per K-step).
+#ifndef G_T96_MIN_TILES
+#define G_T96_MIN_TILES 1000
+#endif
 #ifndef G_FILL_RATIO
 #define G_FILL_RATIO 1.12
 #endif
 #ifndef G_NST_SWITCH_TILES
-#define G_NST_SWITCH_TILES 500
+#define G_NST_SWITCH_TILES 1000
 #endif
 #define G_NUM_CU 256
 #ifndef G_SMALL_TILES
@@ -358,7 +361,16 @@ template <int BN_, int G_NST, int BM_ = G_BM> constexpr int gemm_lds_bytes() {
 // a scalar, a lane keeps one byte offset per piece (its pixel) and a bit per tap (inside the image or padding), and
 // the K loop carries no per-lane index arithmetic beyond one 64-bit add and the zero-page select.
 template <int BN_, int G_NST, int CONV, typename OutT, int BM_ = G_BM>
-__global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? 4 : 2)) void gemm_bf16_kernel(GemmP p) {
+// Single-stage instantiations: dense operands at three workgroups per CU (168 registers, no spills) - four (128
+// registers) is faster for some products run alone, but with two or three streams sharing the chip the step is
+// 2.5 % faster at three; the convolution form stays at four (no difference in the step, faster alone).
+#ifndef G_OCC1
+#define G_OCC1 3
+#endif
+#ifndef G_OCC1C
+#define G_OCC1C 4
+#endif
+__global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : G_OCC1) : 2)) void gemm_bf16_kernel(GemmP p) {
     static_assert(BM_ % 32 == 0 && (BM_ == G_BM || !CONV), "row tile: 4 x whole pieces per wave; conv cursors assume 128");
     constexpr int MI = BM_ / 32;                              // 16-row sub-tiles per wave (two waves stacked in M)
     constexpr int APIECES = BM_ / 8, BPIECES = BN_ / 8;       // 1-KiB pieces (8 rows x 128 B)
@@ -745,7 +757,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
             const long rounds = (t + G_NUM_CU - 1) / G_NUM_CU;
             return (double)M * tnn / ((double)rounds * G_NUM_CU * rows);
         };
-        if (t96 >= G_NST_SWITCH_TILES && fill(t96, 96, p.M, tn) > G_FILL_RATIO * fill(t128, 128, p.M, tn)) bm = 96;
+        if (t96 >= G_T96_MIN_TILES && fill(t96, 96, p.M, tn) > G_FILL_RATIO * fill(t128, 128, p.M, tn)) bm = 96;
     }
     // 256-row tiles (a wave owns 128 x 64: a quarter less LDS traffic per MFMA) pay off only where the tile
     // count stays far above the CU count: +8 % on 4096^3 and larger, a loss on every product of this network.
