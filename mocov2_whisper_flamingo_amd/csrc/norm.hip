@@ -377,6 +377,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* __restrict__ x,
     }
 }
 
+#ifndef BN_APPLY_BLOCKS
+#define BN_APPLY_BLOCKS 4096
+#endif
 // bf16 -> bf16 form for channel counts that are a multiple of 8 with 16-byte-aligned operands: 8 channels per
 // thread as one 16-byte load / store.  A thread's channel group is fixed when the grid stride is a multiple of
 // C/8 (the host rounds it), so scale and shift live in registers for the whole kernel and the loop is load,
@@ -459,7 +462,7 @@ extern "C" int avsr_bn_apply(avsr_stream_t stream, int in_dtype, int out_dtype, 
         // grid stride = 256 * blocks must be a multiple of C8: blocks a multiple of C8 / gcd(C8, 256)
         long unit = 1;
         if (C8 > 256) unit = C8 / 256;                          // C8 is then a multiple of 256
-        long blocks = std::min<long>((n8 + 511) / 512, 2048);
+        long blocks = std::min<long>((n8 + 511) / 512, BN_APPLY_BLOCKS);
         blocks = std::max<long>(unit, blocks / unit * unit);
         if (C8 <= 256 && 256 % C8 != 0) blocks = 0;             // not reached: the test above admits powers of two only
         if (blocks > 0) {

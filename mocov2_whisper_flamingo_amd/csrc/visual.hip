@@ -142,7 +142,7 @@ __global__ void stem3d_pack_frags_kernel(const float* __restrict__ wpacked, bf16
 // phase of the other).  Statistics of item i go to slab row clip*parts_per_clip + i; the rows of a clip no
 // item owns are zeroed by the clip's first item.
 #define SM_F 4
-__global__ __launch_bounds__(256) void stem3d_mfma_kernel(const float* __restrict__ video, const bf16_t* __restrict__ frags,
+__global__ __launch_bounds__(256, 2) void stem3d_mfma_kernel(const float* __restrict__ video, const bf16_t* __restrict__ frags,
                                                          bf16_t* __restrict__ out, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float* __restrict__ csum,
                                                          float* __restrict__ csq, int B, int T, int H, int W, int OH, int OW,
