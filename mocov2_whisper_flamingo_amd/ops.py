@@ -4,7 +4,6 @@ and launches on torch's current stream.  torch only provides device memory and
 the stream.
 """
 import ctypes
-import os
 import torch
 
 from . import _lib
