@@ -186,7 +186,7 @@ def _bthd(t, H):
     """[B,T,*] view whose last dim holds H heads of 64 starting at the view's offset."""
     if t.dim() != 3 or t.stride(2) != 1:
         raise ValueError("attention operands must be [B,T,H*64] views with unit inner stride")
-    if t.stride(0) != t.shape[1] * t.stride(1):
+    if t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1):
         raise ValueError("attention operands must have batch stride = T * row stride")
     return t.stride(1)
 

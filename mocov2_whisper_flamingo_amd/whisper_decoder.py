@@ -5,10 +5,13 @@ names of ``whisper_model.decoder.*`` (the reference constructs the decoder with
 arithmetic is HF ``WhisperDecoder`` / ``WhisperDecoderLayer``,
 modeling_whisper.py:649-797 / 416-505).
 
-Forward only and cache-less: the whole token sequence is decoded in one pass
-(teacher forcing / scoring); ``cross_kv`` exposes the per-layer encoder
-projections so a caller that decodes several hypotheses against one encoder
-output computes them once.
+Forward only.  ``forward`` decodes a whole token sequence in one pass (teacher
+forcing / scoring); ``new_cache`` + ``decode_step`` decode incrementally with the
+self-attention keys / values of earlier tokens kept in a cache (what HF's
+``DynamicCache`` holds, hf:649-797 ``past_key_values``), the causal attention
+kernel taking the new tokens as the LAST queries of the cached sequence.
+``cross_kv`` exposes the per-layer encoder projections so they are computed
+once per encoder output.
 """
 import torch
 import torch.nn as nn
@@ -128,6 +131,79 @@ class WhisperDecoder(nn.Module):
             ops.gemm_nt(f, lw["wfc2"], bias=lw["bfc2"], residual=xs, out=xs)
         out = ops.layernorm_fwd(xs, *pk["lnf"], out_dtype=dtype)
         return (out.view(B, T, D),)
+
+    @torch.no_grad()
+    def new_cache(self, batch, encoder_hidden_states=None, dtype=torch.bfloat16, max_tokens=None, device=None):
+        """An empty decoding state for ``batch`` sequences: per-layer [B, max_tokens, 2D] key|value buffers
+        (filled front to back by :meth:`decode_step`) and the encoder projections."""
+        cfg = self.cfg
+        n = cfg.max_target_positions if max_tokens is None else int(max_tokens)
+        if n > cfg.max_target_positions:
+            raise ValueError(f"max_tokens exceeds max_target_positions={cfg.max_target_positions}")
+        device = device or self.embed_tokens.weight.device
+        return {"len": 0, "dtype": dtype,
+                "kv": [torch.empty((batch, n, 2 * cfg.d_model), dtype=dtype, device=device) for _ in self.layers],
+                "cross": None if encoder_hidden_states is None else self.cross_kv(encoder_hidden_states, dtype)}
+
+    @torch.no_grad()
+    def decode_step(self, input_ids, cache):
+        """Appends ``input_ids`` [B, t] (one token per call in greedy decoding, or a whole prompt) to the
+        sequences in ``cache`` and returns their hidden states [B, t, D]: the same values ``forward`` gives
+        for these positions of the full sequence (no padding mask: every cached token is attended)."""
+        cfg = self.cfg
+        dtype = cache["dtype"]
+        B, T = input_ids.shape
+        past = cache["len"]
+        if past + T > cache["kv"][0].shape[1]:
+            raise ValueError("decoding past the cache's max_tokens")
+        pk = self._pack(dtype)
+        H, D = cfg.decoder_attention_heads, cfg.d_model
+        use_mfma = dtype == torch.bfloat16
+        xs = ops.embed_tokens(input_ids, pk["tok"], pk["pos"], past=past)
+        for i, lw in enumerate(pk["layers"]):
+            h = ops.layernorm_fwd(xs, *lw["ln1"], out_dtype=dtype)
+            qkv = ops.gemm_nt(h, lw["wqkv"], bias=lw["bqkv"]).view(B, T, 3 * D)
+            kv = cache["kv"][i]
+            for b in range(B):                                  # this step's keys | values behind the cached ones
+                ops.cast_rows(qkv[b, :, D:], kv[b, past:past + T])
+            seen = kv[:, :past + T]
+            if B > 1 and past + T < kv.shape[1]:                # the kernel's batch stride is Tk rows: pack the filled part
+                seen = seen.contiguous()
+            o = ops.attn_fwd(qkv[:, :, :D], seen[:, :, :D], seen[:, :, D:], H, scale=1.0, use_mfma=use_mfma, causal=True)
+            ops.gemm_nt(o.view(B * T, D), lw["wo"], bias=lw["bo"], residual=xs, out=xs)
+            if cache["cross"] is not None:
+                ckv = cache["cross"][i]
+                h = ops.layernorm_fwd(xs, *lw["lnx"], out_dtype=dtype)
+                q = ops.gemm_nt(h, lw["wq_x"], bias=lw["bq_x"]).view(B, T, D)
+                o = ops.attn_fwd(q, ckv[:, :, :D], ckv[:, :, D:], H, scale=1.0, use_mfma=use_mfma)
+                ops.gemm_nt(o.view(B * T, D), lw["wo_x"], bias=lw["bo_x"], residual=xs, out=xs)
+            h = ops.layernorm_fwd(xs, *lw["ln2"], out_dtype=dtype)
+            f = ops.gemm_nt(h, lw["wfc1"], bias=lw["bfc1"], act=ops.ACT_GELU)
+            ops.gemm_nt(f, lw["wfc2"], bias=lw["bfc2"], residual=xs, out=xs)
+        cache["len"] = past + T
+        return ops.layernorm_fwd(xs, *pk["lnf"], out_dtype=dtype).view(B, T, D)
+
+    @torch.no_grad()
+    def greedy(self, prompt_ids, encoder_hidden_states, max_new_tokens, eos_token_id=None, dtype=torch.bfloat16):
+        """Greedy decoding with the tied output projection: returns int64 [B, prompt + generated] (stops early
+        when every sequence has produced ``eos_token_id``)."""
+        B, P = prompt_ids.shape
+        cache = self.new_cache(B, encoder_hidden_states, dtype, max_tokens=min(self.cfg.max_target_positions, P + max_new_tokens))
+        out = [prompt_ids]
+        h = self.decode_step(prompt_ids, cache)
+        done = torch.zeros(B, dtype=torch.bool, device=prompt_ids.device)
+        for _ in range(max_new_tokens):
+            logits = self.project_tokens(h[:, -1:, :].contiguous())
+            nxt = ops.argmax_rows(logits.view(B, -1)).view(B, 1)
+            out.append(nxt)
+            if eos_token_id is not None:
+                done |= nxt.view(B) == eos_token_id
+                if bool(done.all()):
+                    break
+            if cache["len"] >= cache["kv"][0].shape[1]:
+                break
+            h = self.decode_step(nxt, cache)
+        return torch.cat(out, dim=1)
 
     @torch.no_grad()
     def project_tokens(self, hidden, out_dtype=torch.float32):

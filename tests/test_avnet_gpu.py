@@ -78,6 +78,54 @@ def test_whisper_decoder(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_whisper_decoder_incremental(dev, dtype):
+    """Key/value-cached decoding: a prompt then one token per call gives the hidden states the oracle (and the
+    one-pass forward) gives for the whole sequence; greedy decoding reproduces the token ids an argmax over the
+    oracle's logits yields step by step (fp32: bit-exact ids)."""
+    cfg = WhisperConfig(d_model=128, decoder_layers=2, decoder_attention_heads=2, vocab_size=503, max_target_positions=448)
+    m = WhisperModel(cfg)
+    sd = seed_module(m, 23)
+    m.to(dev)
+    g = torch.Generator().manual_seed(4)
+    for B in (1, 3):
+        T, P, Te = 21, 5, 70
+        ids = torch.randint(3, 503, (B, T), generator=g)
+        enc = torch.randn(B, Te, 128, generator=g)
+        ref = oracle.whisper_decoder(sd, "decoder.", ids, enc, 2)
+        cache = m.decoder.new_cache(B, enc.to(dev), dtype, max_tokens=32)
+        parts = [m.decoder.decode_step(ids[:, :P].to(dev), cache)]
+        for t in range(P, T):
+            parts.append(m.decoder.decode_step(ids[:, t:t + 1].to(dev), cache))
+        got = torch.cat(parts, dim=1)
+        assert cache["len"] == T and got.shape == ref.shape
+        assert max_err(got, ref) < TOL[dtype]
+        full = m.decoder(ids.to(dev), encoder_hidden_states=enc.to(dev), dtype=dtype)[0]
+        assert max_err(got, full.float().cpu()) < TOL[dtype]
+        # a cache exactly as long as the sequence (no packing copy on the last step)
+        cache = m.decoder.new_cache(B, enc.to(dev), dtype, max_tokens=T)
+        m.decoder.decode_step(ids[:, :T - 1].to(dev), cache)
+        last = m.decoder.decode_step(ids[:, T - 1:].to(dev), cache)
+        assert max_err(last, ref[:, T - 1:]) < TOL[dtype]
+        with pytest.raises(ValueError):
+            m.decoder.decode_step(ids[:, :1].to(dev), cache)
+    if dtype == torch.float32:
+        B, P, N = 2, 3, 9
+        prompt = torch.randint(3, 503, (B, P), generator=g)
+        enc = torch.randn(B, 50, 128, generator=g)
+        want = prompt.clone()
+        for _ in range(N):
+            h = oracle.whisper_decoder(sd, "decoder.", want, enc, 2)
+            nxt = (h[:, -1] @ sd["decoder.embed_tokens.weight"].t()).argmax(-1, keepdim=True)
+            want = torch.cat([want, nxt], dim=1)
+        got = m.decoder.greedy(prompt.to(dev), enc.to(dev), N, dtype=dtype)
+        assert torch.equal(got.cpu(), want)
+        # stops when every sequence has produced the end token
+        eos = int(want[0, P].item())
+        short = m.decoder.greedy(prompt[:1].to(dev), enc[:1].to(dev), N, eos_token_id=eos, dtype=dtype)
+        assert short.shape[1] == P + 1 and int(short[0, -1]) == eos
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("training", [False, True])
 def test_visual_frontend(dev, dtype, training):
     m = MoCoVisualFrontend()
