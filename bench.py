@@ -17,6 +17,16 @@ import os
 import sys
 import time
 
+# The step keeps several streams busy at once (the trainable tail, the two frozen encoders replayed from their graph,
+# the collective library's stream).  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues in creation order, and two
+# streams that land on one queue run strictly in issue order: the tail behind the next batch's encoders costs ~2 ms a
+# step.  Eight queues keep them apart whatever else the process creates first; it has to be set before HIP starts.
+try:
+    if int(os.environ.get("GPU_MAX_HW_QUEUES") or 4) < 8:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+except ValueError:
+    pass
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -93,6 +103,9 @@ def main():
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="launch each bucket's all-reduce from gradient hooks on a side stream during backward")
     ap.add_argument("--rehearse-backend", default=None, help="e.g. gloo: rehearse N ranks on fewer GPUs (not a measurement)")
+    ap.add_argument("--grad-stream", default="auto", choices=["auto", "on", "off"],
+                    help="parameter-gradient kernels on a stream of their own beside the dX chain; auto = only without "
+                         "the pipeline (with it, the step time then hinges on which hardware queue that stream lands on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -111,9 +124,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.rehearse_backend:
         if args.rehearse_backend:
-            dist.init_process_group(args.rehearse_backend)
+            # also valid with one rank (`--rehearse-backend nccl` without a launcher): the collectives are then
+            # issued over a one-rank communicator, which exercises the RCCL call path beside the graph replays
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if args.rehearse_backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(args.rehearse_backend)
         else:
             dist.init_process_group("nccl", device_id=dev)
 
@@ -132,7 +154,8 @@ def main():
     model.train(args.mode == "train")
     # With the next batch's encoders running beside this batch's tail, the gradient exchange is hidden along with
     # the rest of the tail: it is issued in stream order after backward (two 64 MB-class buckets), not from hooks.
-    trainer = FlatTrainer(model, lr=1e-3, bucket_mb=64, overlap=args.overlap_allreduce)
+    trainer = FlatTrainer(model, lr=1e-3, bucket_mb=64, overlap=args.overlap_allreduce,
+                          force_collective=bool(args.rehearse_backend), grad_stream=args.grad_stream == "on" or (args.grad_stream == "auto" and not args.pipeline))
     B, T = args.batch, 75 * windows
     batch = synthetic_batch(B, T, 96, 96, 1234 + rank, dev, mel_frames=3000 * windows)
 
@@ -170,7 +193,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -185,7 +208,7 @@ def main():
         loss = run(args.steps)
         barrier()
         dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -239,7 +262,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -38,7 +38,7 @@ class FlatTrainer:
     """
 
     def __init__(self, model, *, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_grad_norm=1.0,
-                 bucket_mb=64, process_group=None, overlap=True):
+                 bucket_mb=64, process_group=None, overlap=True, force_collective=False, grad_stream=True):
         self.model = model
         self.named = trainable_parameters(model)
         if not self.named:
@@ -49,6 +49,8 @@ class FlatTrainer:
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # force_collective: issue the all-reduces even at world size 1 (a rehearsal of the collective call path)
+        self.collective = self.world > 1 or (force_collective and dist.is_available() and dist.is_initialized())
         self.step_count = 0
 
         # backward reaches parameters roughly in reverse registration order: lay the flat buffer out in
@@ -83,13 +85,13 @@ class FlatTrainer:
         if pending:
             self.buckets.append({"range": (start, total), "params": pending, "left": 0})
         self._bucket_of = {id(p): b for b in self.buckets for p in b["params"]}
-        self.overlap = overlap and self.world > 1
+        self.overlap = overlap and self.collective
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.on_gpu and self.overlap) else None
         self._works = []
         # the backward kernels accumulate straight into the flat gradient buffer (functional.grad_sink);
         # gradients that still arrive through autograd keep the ordinary post-accumulate hook
         # ... on a stream of their own, beside the dX chain of backward
-        self.grad_stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
+        self.grad_stream = torch.cuda.Stream(device=dev) if (self.on_gpu and grad_stream) else None
         from . import functional as Fn
         Fn.GRAD_STREAM = self.grad_stream
         for _, p in self.named:
@@ -153,7 +155,7 @@ class FlatTrainer:
         """Finish the all-reduce of every bucket (launching those the hooks did not) and
         turn the sums into means."""
         self.join_gradients()
-        if self.world == 1:
+        if not self.collective:
             return
         if not self.overlap:
             # no hooks: every gradient is in place and the current stream has joined the gradient stream, so the
