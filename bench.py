@@ -155,7 +155,7 @@ def main():
     # With the next batch's encoders running beside this batch's tail, the gradient exchange is hidden along with
     # the rest of the tail: it is issued in stream order after backward (two 64 MB-class buckets), not from hooks.
     trainer = FlatTrainer(model, lr=1e-3, bucket_mb=64, overlap=args.overlap_allreduce,
-                          force_collective=bool(args.rehearse_backend), grad_stream=args.grad_stream == "on" or (args.grad_stream == "auto" and not args.pipeline))
+                          force_collective=bool(args.rehearse_backend), fused_step=True, grad_stream=args.grad_stream == "on" or (args.grad_stream == "auto" and not args.pipeline))
     B, T = args.batch, 75 * windows
     batch = synthetic_batch(B, T, 96, 96, 1234 + rank, dev, mel_frames=3000 * windows)
 

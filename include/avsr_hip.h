@@ -300,13 +300,17 @@ int avsr_embed_tokens(avsr_stream_t stream, int table_dtype, const int64_t* ids,
 
 /* ------------------------------------------------------------------------
  * Optimizer step of train.py:218-225,321: global-norm clipping and AdamW over
- * flat fp32 buffers.  *out += sum(x^2);  *scale = min(1, max_norm/(norm+1e-6)).
+ * flat fp32 buffers.  *out += sum(x^2);  norm = pre_scale*sqrt(sumsq);
+ * *scale = pre_scale * min(1, max_norm/(norm+1e-6)): clipping of pre_scale * gradient
+ * (pre_scale = 1/world folds DDP's mean over ranks, train.py:319, into the step).
+ * clear_grad != 0: the step leaves grad zeroed (optimizer.zero_grad of the next step).
  * ---------------------------------------------------------------------- */
 int avsr_sumsq_accumulate(avsr_stream_t stream, const float* x, int64_t n, float* out);
-int avsr_clip_scale(avsr_stream_t stream, const float* sumsq, float max_norm, float* scale, float* norm_out);
-int avsr_adamw_step(avsr_stream_t stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+int avsr_clip_scale(avsr_stream_t stream, const float* sumsq, float max_norm, float pre_scale, float* scale,
+                    float* norm_out);
+int avsr_adamw_step(avsr_stream_t stream, float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                     void* bf16_shadow, int64_t n, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, int64_t step, const float* grad_scale);
+                    float weight_decay, int64_t step, const float* grad_scale, int clear_grad);
 
 #ifdef __cplusplus
 }

@@ -79,8 +79,8 @@ SIGNATURES = {
     "avsr_add3": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64]),
     "avsr_embed_tokens": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp]),
     "avsr_sumsq_accumulate": (_i32, [_vp, _vp, _i64, _vp]),
-    "avsr_clip_scale": (_i32, [_vp, _vp, _f32, _vp, _vp]),
-    "avsr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _vp]),
+    "avsr_clip_scale": (_i32, [_vp, _vp, _f32, _f32, _vp, _vp]),
+    "avsr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _vp, _i32]),
 }
 
 _lib = None

@@ -159,8 +159,24 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
     __shared__ float red[16];
     const long stride = (long)gridDim.x * blockDim.x;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     float acc = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += x[i] * x[i];
+    if (((uintptr_t)x & 15) == 0) {                       // 16-byte loads over the aligned body, scalars over the tail
+        const long n4 = n >> 2;
+        const float4* x4 = (const float4*)x;
+        float a0 = 0.f, a1 = 0.f;
+        long i = tid;
+        for (; i + stride < n4; i += 2 * stride) {
+            const float4 u = x4[i], w = x4[i + stride];
+            a0 += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
+            a1 += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+        }
+        if (i < n4) { const float4 u = x4[i]; a0 += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w; }
+        acc = a0 + a1;
+        for (long j = (n4 << 2) + tid; j < n; j += stride) acc += x[j] * x[j];
+    } else {
+        for (long i = tid; i < n; i += stride) acc += x[i] * x[i];
+    }
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) atomicAdd(out, acc);
 }
@@ -168,15 +184,17 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // AdamW over a flat fp32 parameter buffer (torch.optim.AdamW semantics:
 // decoupled weight decay, bias-corrected moments, eps added to sqrt(v_hat)).
 // grad_scale[0] multiplies the gradient first (global-norm clipping factor);
-// a bf16 shadow copy of the new weights is written when `shadow` is set.
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// a bf16 shadow copy of the new weights is written when `shadow` is set; `clear_grad` leaves the gradient
+// buffer zeroed for the next accumulation (saves the separate fill pass).
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, long n, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1, float bc2,
-                                                    const float* __restrict__ grad_scale) {
+                                                    const float* __restrict__ grad_scale, int clear_grad) {
     const float gs = grad_scale ? grad_scale[0] : 1.f;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float gr = g[i] * gs;
+        if (clear_grad) g[i] = 0.f;
         float w = p[i] * (1.f - lr * wd);
         const float mi = beta1 * m[i] + (1.f - beta1) * gr;
         const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
@@ -188,12 +206,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
-// scale[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))   (torch clip_grad_norm_)
-__global__ void clip_scale_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ scale,
-                                  float* __restrict__ norm_out) {
-    const float nrm = sqrtf(sumsq[0]);
+// norm = pre_scale * sqrt(sumsq[0]);  scale[0] = pre_scale * min(1, max_norm / (norm + 1e-6))   (torch
+// clip_grad_norm_ applied to pre_scale * gradient: pre_scale = 1 / world turns summed gradients into means)
+__global__ void clip_scale_kernel(const float* __restrict__ sumsq, float max_norm, float pre_scale,
+                                  float* __restrict__ scale, float* __restrict__ norm_out) {
+    const float nrm = pre_scale * sqrtf(sumsq[0]);
     if (norm_out) norm_out[0] = nrm;
-    scale[0] = fminf(1.f, max_norm / (nrm + 1e-6f));
+    scale[0] = pre_scale * fminf(1.f, max_norm / (nrm + 1e-6f));
 }
 
 // --------------------------------------------------------------- host ------
@@ -375,23 +394,25 @@ extern "C" int avsr_sum_parts(avsr_stream_t stream, int out_dtype, const float* 
 
 extern "C" int avsr_sumsq_accumulate(avsr_stream_t stream, const float* x, int64_t n, float* out) {
     if (!x || !out || n <= 0) return AVSR_EINVAL;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 2048, 2048)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
     return avsr_launch_status();
 }
 
-extern "C" int avsr_clip_scale(avsr_stream_t stream, const float* sumsq, float max_norm, float* scale, float* norm_out) {
-    if (!sumsq || !scale) return AVSR_EINVAL;
-    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, scale, norm_out);
+extern "C" int avsr_clip_scale(avsr_stream_t stream, const float* sumsq, float max_norm, float pre_scale, float* scale,
+                               float* norm_out) {
+    if (!sumsq || !scale || !(pre_scale > 0.f)) return AVSR_EINVAL;
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, pre_scale, scale,
+                       norm_out);
     return avsr_launch_status();
 }
 
-extern "C" int avsr_adamw_step(avsr_stream_t stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+extern "C" int avsr_adamw_step(avsr_stream_t stream, float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                                void* bf16_shadow, int64_t n, float lr, float beta1, float beta2, float eps,
-                               float weight_decay, int64_t step, const float* grad_scale) {
+                               float weight_decay, int64_t step, const float* grad_scale, int clear_grad) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return AVSR_EINVAL;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, (bf16_t*)bf16_shadow, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+                       exp_avg_sq, (bf16_t*)bf16_shadow, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, clear_grad);
     return avsr_launch_status();
 }
 

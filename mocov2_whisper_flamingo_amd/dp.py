@@ -38,7 +38,7 @@ class FlatTrainer:
     """
 
     def __init__(self, model, *, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_grad_norm=1.0,
-                 bucket_mb=64, process_group=None, overlap=True, force_collective=False, grad_stream=True):
+                 bucket_mb=64, process_group=None, overlap=True, force_collective=False, grad_stream=True, fused_step=False):
         self.model = model
         self.named = trainable_parameters(model)
         if not self.named:
@@ -52,6 +52,12 @@ class FlatTrainer:
         # force_collective: issue the all-reduces even at world size 1 (a rehearsal of the collective call path)
         self.collective = self.world > 1 or (force_collective and dist.is_available() and dist.is_initialized())
         self.step_count = 0
+        # fused_step: the mean over ranks and the next step's zero_grad are folded into the optimizer kernels (one
+        # read-modify-write pass and one fill pass over the flat gradient buffer less per step).  Between
+        # reduce_gradients() and step() the buffer then holds the SUM over ranks, and after step() it is zero.
+        self.fused_step = bool(fused_step)
+        self._pre_scale = 1.0
+        self._clean = False
 
         # backward reaches parameters roughly in reverse registration order: lay the flat buffer out in
         # that order so buckets fill front to back as backward proceeds
@@ -144,7 +150,10 @@ class FlatTrainer:
 
     def zero_grad(self):
         self.join_gradients()
-        self.flat_grad.zero_()
+        if self._clean:              # the last optimizer step left the buffer zeroed
+            self._clean = False
+        else:
+            self.flat_grad.zero_()
         for n, p in self.named:          # keep .grad pointing into the flat buffer
             if p.grad is None:
                 o, s = self.slices[n]
@@ -171,7 +180,7 @@ class FlatTrainer:
                     view.copy_(host)
                 else:
                     dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat_grad.mul_(1.0 / self.world)
+            self._to_mean()
             return
         for b in self.buckets:
             if b["left"] > 0:                         # unused parameter in the bucket
@@ -181,7 +190,13 @@ class FlatTrainer:
         self._works.clear()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
-        self.flat_grad.mul_(1.0 / self.world)
+        self._to_mean()
+
+    def _to_mean(self):
+        if self.fused_step:
+            self._pre_scale = 1.0 / self.world       # applied by the clip / AdamW kernels
+        elif self.world > 1:
+            self.flat_grad.mul_(1.0 / self.world)
 
     def join_gradients(self):
         """Make the current stream wait for the parameter-gradient kernels queued on ``grad_stream``."""
@@ -197,9 +212,12 @@ class FlatTrainer:
         scr = self._scratch
         scr.zero_()
         ops.sumsq_accumulate(self.flat_grad, scr[0:1])
-        ops.clip_scale(scr[0:1], self.max_norm, scr[1:2], scr[2:3])
+        ops.clip_scale(scr[0:1], self.max_norm, scr[1:2], scr[2:3], pre_scale=self._pre_scale)
         ops.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, lr=lr,
-                       betas=self.betas, eps=self.eps, weight_decay=self.wd, grad_scale=scr[1:2])
+                       betas=self.betas, eps=self.eps, weight_decay=self.wd, grad_scale=scr[1:2],
+                       clear_grad=self.fused_step)
+        self._pre_scale = 1.0
+        self._clean = self.fused_step
         # parameters changed in place behind torch's back: drop the compute-dtype weight copies
         cache = getattr(self.model, "_cache", None)
         if cache is not None:

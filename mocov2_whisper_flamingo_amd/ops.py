@@ -563,14 +563,16 @@ def sumsq_accumulate(x, out):
     check(lib.avsr_sumsq_accumulate(_stream(), x.data_ptr(), x.numel(), out.data_ptr()), "avsr_sumsq_accumulate")
 
 
-def clip_scale(sumsq, max_norm, scale, norm_out=None):
+def clip_scale(sumsq, max_norm, scale, norm_out=None, pre_scale=1.0):
+    """scale[0] = pre_scale * min(1, max_norm / (pre_scale * sqrt(sumsq[0]) + 1e-6)); norm_out[0] = the norm."""
     lib = _lib.load()
-    check(lib.avsr_clip_scale(_stream(), sumsq.data_ptr(), max_norm, scale.data_ptr(), _p(norm_out)), "avsr_clip_scale")
+    check(lib.avsr_clip_scale(_stream(), sumsq.data_ptr(), max_norm, pre_scale, scale.data_ptr(), _p(norm_out)),
+          "avsr_clip_scale")
 
 
 def adamw_step(param, grad, exp_avg, exp_avg_sq, step, *, lr, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01,
-               grad_scale=None, bf16_shadow=None):
+               grad_scale=None, bf16_shadow=None, clear_grad=False):
     lib = _lib.load()
     check(lib.avsr_adamw_step(_stream(), param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                               _p(bf16_shadow), param.numel(), lr, betas[0], betas[1], eps, weight_decay, step,
-                              _p(grad_scale)), "avsr_adamw_step")
+                              _p(grad_scale), int(bool(clear_grad))), "avsr_adamw_step")

@@ -513,7 +513,10 @@ def _dp_gpu_worker(rank, world, port, q):
         torch.cuda.set_device(dev)
         m, sd = _micro_avnet(torch.float32, dev, p_drop=0.0)
         m.eval()                                             # running-statistics BN: the full batch and its halves agree
-        tr = FlatTrainer(m, bucket_mb=0.25, overlap=bool(int(os.environ.get("AVSR_TEST_OVERLAP", "1"))))    # small buckets: several all-reduces launched from the hooks
+        mode = os.environ.get("AVSR_TEST_OVERLAP", "1")
+        fused = mode == "fused"        # the benchmark's trainer: in-stream reduction, no gradient stream, mean and zeroing in the step
+        # small buckets: several all-reduces (launched from the hooks when overlap is on)
+        tr = FlatTrainer(m, bucket_mb=0.25, overlap=mode == "1", grad_stream=not fused, fused_step=fused)
         full = synthetic_batch(B=2 * world, Tv=6, H=32, W=32, L=4, vocab=503, seed=3)
         mine = to_device({k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}, dev)
         tr.zero_grad()
@@ -525,9 +528,20 @@ def _dp_gpu_worker(rank, world, port, q):
         if rank == 0:
             _, _, _, _, ref, _ = oracle.training_step(sd, full, 2, 2, training=False, masked_row="zero")
             params = dict(m.named_parameters())
-            errs = {k: ((params[k].grad.cpu() - ref[k]).abs().max() / ref[k].abs().max().clamp_min(1e-6)).item()
+            mean = (1.0 / world) if fused else 1.0              # fused: the buffer holds the sum until the step
+            errs = {k: ((params[k].grad.cpu() * mean - ref[k]).abs().max() / ref[k].abs().max().clamp_min(1e-6)).item()
                     for k in ref}
             worst = max(errs.values())
+            if fused:                                            # the step applies the mean, clips and clears
+                tr.step()
+                want = torch.sqrt(sum((ref[k].double() ** 2).sum() for k, _ in tr.named)).item()
+                got = float(tr.grad_norm().item())
+                clip = float(tr._scratch[1].item())
+                assert abs(got - want) <= 1e-3 * want, (got, want)
+                assert abs(clip - mean * min(1.0, 1.0 / (want + 1e-6))) <= 1e-3 * mean, clip
+                assert float(tr.flat_grad.abs().max().item()) == 0.0
+                tr.zero_grad()                                   # nothing to fill: the buffer is already clean
+                assert tr._clean is False
             if worst >= 1e-3:
                 print("per-parameter relative errors:", {k: round(v, 4) for k, v in errs.items() if v >= 1e-3}, flush=True)
             q.put(("ok", worst, len(tr.buckets)))
@@ -540,7 +554,7 @@ def _dp_gpu_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", ["1", "0"])
+@pytest.mark.parametrize("overlap", ["1", "0", "fused"])
 def test_dp_hooks_and_direct_gradients_two_ranks_one_gpu(dev, overlap, monkeypatch):
     """Two ranks (gloo, both on this GPU) run the HIP training step on half a batch each with FlatTrainer's
     bucket hooks, gradient stream and communication stream active; the averaged gradients must equal the
@@ -565,3 +579,33 @@ def test_dp_hooks_and_direct_gradients_two_ranks_one_gpu(dev, overlap, monkeypat
     assert status == "ok", worst
     assert all(p.exitcode == 0 for p in procs)
     assert nb > 1 and worst < 1e-3
+
+
+def test_flat_trainer_fused_step_matches_plain(dev):
+    """fused_step (mean, clip, AdamW and the next zero_grad in the optimizer kernels) walks the same parameter
+    trajectory as the plain trainer over three steps and leaves the gradient buffer zeroed."""
+    from mocov2_whisper_flamingo_amd.dp import FlatTrainer
+    ms = [_micro_avnet(torch.float32, dev, p_drop=0.0)[0] for _ in range(2)]
+    trs = [FlatTrainer(ms[0]), FlatTrainer(ms[1], fused_step=True, grad_stream=False)]
+    batch = to_device(synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=8), dev)
+    for m in ms:
+        m.eval()
+        with torch.no_grad():
+            for blk in m.fusion_module.layers:
+                blk.attn_gate.fill_(0.4)
+                blk.ff_gate.fill_(-0.3)
+    for _ in range(3):
+        for m, tr in zip(ms, trs):
+            b = dict(batch)
+            b["video_lengths"] = batch["video_lengths"].clone()
+            tr.zero_grad()
+            loss, *_ = m.training_step(b)
+            loss.backward()
+            tr.reduce_gradients()
+            tr.step(lr=1e-3)
+        assert float(trs[1].flat_grad.abs().max().item()) == 0.0
+    torch.cuda.synchronize()
+    na, nb = float(trs[0].grad_norm().item()), float(trs[1].grad_norm().item())
+    assert abs(na - nb) <= 1e-5 * na
+    # fp32 atomics order the dW partial sums differently from run to run: equal to rounding, not bit for bit
+    assert float((trs[0].flat_param - trs[1].flat_param).abs().max()) <= 1e-5
