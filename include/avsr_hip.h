@@ -231,9 +231,12 @@ int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq,
                      float* scale, float* shift, int64_t C, float eps, float momentum, float* ws, int32_t* tickets);
 int avsr_bn_fold(avsr_stream_t stream, const float* weight, const float* bias, const float* running_mean,
                  const float* running_var, float* scale, float* shift, int64_t C, float eps);
-/* y = act(x*scale + shift (+ residual)); x may be fp32 while y / residual are bf16 */
+/* y = act(x*scale + shift (+ residual)); x may be fp32 while y / residual are bf16.  res_scale / res_shift
+ * (both or neither; need a residual): the residual is a raw convolution output with a BN of its own and no
+ * activation - the downsample branch of torchvision's Bottleneck - applied here: + residual*res_scale + res_shift. */
 int avsr_bn_apply(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, const void* residual, void* y,
-                  const float* scale, const float* shift, int64_t rows, int64_t C, int relu);
+                  const float* scale, const float* shift, const float* res_scale, const float* res_shift,
+                  int64_t rows, int64_t C, int relu);
 
 /* ------------------------------------------------------------------------
  * Head losses on fp32 logits [B*T, V] (train.py:95-128,137): row

@@ -61,7 +61,7 @@ SIGNATURES = {
     "avsr_gemm_stats_parts": (_i64, [_i32, _i64]),
     "avsr_stem3d_stats_parts": (_i64, [_i64, _i64, _i64, _i64]),
     "avsr_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32]),
-    "avsr_bn_apply": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32]),
+    "avsr_bn_apply": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32]),
     "avsr_head_loss_workspace_floats": (_i64, [_i64, _i64, _i64]),
     "avsr_head_loss_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _i64, _i64, _vp, _vp]),
     "avsr_head_loss_bwd": (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _i64, _i64,

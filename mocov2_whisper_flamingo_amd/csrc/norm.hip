@@ -357,6 +357,7 @@ __global__ void bn_fold_kernel(const float* __restrict__ weight, const float* __
 template <typename TI, typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                        long n4, int C, int relu) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -368,6 +369,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* __restrict__ x,
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
         if (res) { float r[4]; load4<T>(res + i * 4, r);
+            if (rscale) { float a[4], b[4]; load4<float>(rscale + c, a); load4<float>(rshift + c, b);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = r[e] * a[e] + b[e]; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += r[e]; }
         if (relu) {
@@ -384,15 +388,24 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* __restrict__ x,
 // thread as one 16-byte load / store.  A thread's channel group is fixed when the grid stride is a multiple of
 // C/8 (the host rounds it), so scale and shift live in registers for the whole kernel and the loop is load,
 // 8 fma, (add, max), store: two independent 16-byte loads in flight per thread and iteration.
+// RA: the residual is itself a raw convolution output with an affine of its own (the downsample branch's BN,
+// which has no activation): y = act(x*scale + shift + res*rscale + rshift).
+template <bool RA>
 __global__ __launch_bounds__(256) void bn_apply_bf16x8_kernel(const bf16_t* x, const bf16_t* res,   // y may be x
                                                               bf16_t* y, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, long n8, int C8, int relu) {
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ rscale,
+                                                              const float* __restrict__ rshift, long n8, int C8, int relu) {
     const long stride = (long)gridDim.x * blockDim.x;          // multiple of C8
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c = (int)(i % C8) * 8;
-    float sc[8], sh[8];
+    float sc[8], sh[8], rs[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = scale[c + e]; sh[e] = shift[c + e]; }
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[c + e]; sh[e] = shift[c + e]; rs[e] = 1.f; }
+    if (RA) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { rs[e] = rscale[c + e]; sh[e] += rshift[c + e]; }   // both shifts add up front
+    }
     for (; i < n8; i += 2 * stride) {
         const long j = i + stride;
         const bool two = j < n8;
@@ -404,7 +417,8 @@ __global__ __launch_bounds__(256) void bn_apply_bf16x8_kernel(const bf16_t* x, c
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v0 = fmaf((float)a0[e], sc[e], sh[e]), v1 = fmaf((float)a1[e], sc[e], sh[e]);
-            if (res) { v0 += (float)r0[e]; v1 += (float)r1[e]; }
+            if (RA) { v0 = fmaf((float)r0[e], rs[e], v0); v1 = fmaf((float)r1[e], rs[e], v1); }
+            else if (res) { v0 += (float)r0[e]; v1 += (float)r1[e]; }
             if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
             o0[e] = (bf16_t)v0; o1[e] = (bf16_t)v1;
         }
@@ -451,8 +465,10 @@ extern "C" int avsr_bn_fold(avsr_stream_t stream, const float* weight, const flo
 }
 
 extern "C" int avsr_bn_apply(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, const void* residual,
-                             void* y, const float* scale, const float* shift, int64_t rows, int64_t C, int relu) {
+                             void* y, const float* scale, const float* shift, const float* res_scale,
+                             const float* res_shift, int64_t rows, int64_t C, int relu) {
     if (!x || !y || !scale || !shift || rows <= 0 || C <= 0) return AVSR_EINVAL;
+    if ((res_scale != nullptr) != (res_shift != nullptr) || (res_scale && !residual)) return AVSR_EINVAL;
     if (C % 4) return AVSR_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (in_dtype == AVSR_BF16 && out_dtype == AVSR_BF16 && C % 8 == 0 && (2048 % (C / 8) == 0 || (C / 8) % 256 == 0) &&
@@ -466,8 +482,12 @@ extern "C" int avsr_bn_apply(avsr_stream_t stream, int in_dtype, int out_dtype, 
         blocks = std::max<long>(unit, blocks / unit * unit);
         if (C8 <= 256 && 256 % C8 != 0) blocks = 0;             // not reached: the test above admits powers of two only
         if (blocks > 0) {
-            hipLaunchKernelGGL(bn_apply_bf16x8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x,
-                               (const bf16_t*)residual, (bf16_t*)y, scale, shift, n8, C8, relu);
+            if (res_scale)
+                hipLaunchKernelGGL(bn_apply_bf16x8_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x,
+                                   (const bf16_t*)residual, (bf16_t*)y, scale, shift, res_scale, res_shift, n8, C8, relu);
+            else
+                hipLaunchKernelGGL(bn_apply_bf16x8_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x,
+                                   (const bf16_t*)residual, (bf16_t*)y, scale, shift, res_scale, res_shift, n8, C8, relu);
             return avsr_launch_status();
         }
     }
@@ -475,7 +495,7 @@ extern "C" int avsr_bn_apply(avsr_stream_t stream, int in_dtype, int out_dtype, 
     long nb = (n4 + 255) / 256;
     if (nb > 4096) nb = 4096;
 #define L(TI, TO) hipLaunchKernelGGL((bn_apply_kernel<TI, TO>), dim3((unsigned)nb), dim3(256), 0, s, (const TI*)x, \
-                                     (const TO*)residual, (TO*)y, scale, shift, n4, (int)C, relu)
+                                     (const TO*)residual, (TO*)y, scale, shift, res_scale, res_shift, n4, (int)C, relu)
     if (in_dtype == AVSR_F32 && out_dtype == AVSR_F32) L(float, float);
     else if (in_dtype == AVSR_BF16 && out_dtype == AVSR_BF16) L(bf16_t, bf16_t);
     else if (in_dtype == AVSR_F32 && out_dtype == AVSR_BF16) L(float, bf16_t);

@@ -105,7 +105,9 @@ class MoCoVisualFrontend(nn.Module):
         return self._packed[1]["fold"][id(bn)]
 
     # ---- one conv + BN (+ReLU / + residual) ------------------------------------
-    def _conv_bn(self, x, w, k, stride, pad, bn, relu, residual=None):
+    def _conv_bn(self, x, w, k, stride, pad, bn, relu, residual=None, residual_affine=None, defer=False):
+        """``defer`` (train mode): return (raw conv output, (scale, shift)) without the apply pass, for a consumer that
+        applies the affine itself; ``residual_affine``: such a deferred pair for the residual operand."""
         if not self.training:
             sc, sh = self._fold(bn)
             if residual is not None:
@@ -121,7 +123,9 @@ class MoCoVisualFrontend(nn.Module):
         aff = torch.empty((2, C), dtype=torch.float32, device=x.device)
         ops.bn_finalize(stats[0], stats[1], rows, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                         bn.running_var, aff[0], aff[1], bn.eps, bn.momentum)
-        return ops.bn_apply(raw, aff[0], aff[1], residual=residual, relu=relu, out=raw)
+        if defer:
+            return raw, (aff[0], aff[1])
+        return ops.bn_apply(raw, aff[0], aff[1], residual=residual, residual_affine=residual_affine, relu=relu, out=raw)
 
     @torch.no_grad()
     def run_stem(self, video, pk=None):
@@ -145,12 +149,16 @@ class MoCoVisualFrontend(nn.Module):
         pk = pk or self._pack(self.compute_dtype)
         e = pk["blocks"][index]
         blk = self._blocks[index]
-        idt = y
+        idt, idt_aff = y, None
         if "wd" in e:
-            idt = self._conv_bn(y, e["wd"], 1, e["stride"], 0, blk.downsample[1], relu=False)
+            # batch statistics: the downsample BN has no activation, so its apply pass is folded into bn3's
+            if self.training:
+                idt, idt_aff = self._conv_bn(y, e["wd"], 1, e["stride"], 0, blk.downsample[1], relu=False, defer=True)
+            else:
+                idt = self._conv_bn(y, e["wd"], 1, e["stride"], 0, blk.downsample[1], relu=False)
         h = self._conv_bn(y, e["w1"], 1, 1, 0, blk.bn1, relu=True)
         h = self._conv_bn(h, e["w2"], 3, e["stride"], 1, blk.bn2, relu=True)
-        return self._conv_bn(h, e["w3"], 1, 1, 0, blk.bn3, relu=True, residual=idt)
+        return self._conv_bn(h, e["w3"], 1, 1, 0, blk.bn3, relu=True, residual=idt, residual_affine=idt_aff)
 
     @torch.no_grad()
     def forward(self, x, x_len):

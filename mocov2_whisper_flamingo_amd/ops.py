@@ -402,14 +402,17 @@ def bn_fold(weight, bias, running_mean, running_var, eps=1e-5):
     return scale, shift
 
 
-def bn_apply(x, scale, shift, *, residual=None, relu=True, out=None, out_dtype=None):
+def bn_apply(x, scale, shift, *, residual=None, residual_affine=None, relu=True, out=None, out_dtype=None):
+    """y = act(x*scale + shift (+ residual)).  ``residual_affine=(scale, shift)``: the residual is a raw
+    convolution output whose own (activation-free) BN is applied on the fly."""
     lib = _lib.load()
     C = x.shape[-1]
     y = out if out is not None else torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
     if residual is not None and residual.dtype != y.dtype:
         raise TypeError("residual must have the output dtype")
+    rs, rb = residual_affine if residual_affine is not None else (None, None)
     check(lib.avsr_bn_apply(_stream(), _dt(x), _DT[y.dtype], x.data_ptr(), _p(residual), y.data_ptr(), scale.data_ptr(),
-                            shift.data_ptr(), x.numel() // C, C, int(relu)), "avsr_bn_apply")
+                            shift.data_ptr(), _p(rs), _p(rb), x.numel() // C, C, int(relu)), "avsr_bn_apply")
     return y
 
 

@@ -470,6 +470,13 @@ def test_stem_pool_bn(dev, odt):
     r = rnd(g, 50, 64, dtype=odt)
     ya = ops.bn_apply(x.to(dev, odt), sc, sh, residual=r.to(dev, odt), relu=True)
     assert rel_err(ya, F.relu(x * sc.cpu() + sh.cpu() + r)) < tol(odt)
+    # ... and a residual that still needs its own affine (the downsample branch's BN, folded into this pass);
+    # 4096 rows take the 16-byte bf16 kernel through more than one grid stride
+    for rows in (50, 4096):
+        x, r = rnd(g, rows, 64, dtype=odt), rnd(g, rows, 64, dtype=odt)
+        rs, rb = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+        yb = ops.bn_apply(x.to(dev, odt), sc, sh, residual=r.to(dev, odt), residual_affine=(rs.to(dev), rb.to(dev)), relu=True)
+        assert rel_err(yb, F.relu(x * sc.cpu() + sh.cpu() + r * rs + rb)) < tol(odt)
     # avgpool + mask
     feat = rnd(g, B * T, 4, 4, 128, dtype=odt)
     lens = torch.tensor([3, 4])
