@@ -206,6 +206,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         loss = run(args.steps)
+        t_issue = time.perf_counter() - t0          # host time to enqueue every step (nothing in run() synchronises)
         barrier()
         dt = time.perf_counter() - t0
     if dist.is_initialized():
@@ -258,7 +259,8 @@ def main():
                                    f"clips ({T} frames 96x96) per GPU, {args.mode}-mode BN/dropout, "
                                    + ("fp8 encoder attention, " if args.attention == "fp8" else "")
                                    + "fwd+bwd+all-reduce+clip+AdamW",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
+                       "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

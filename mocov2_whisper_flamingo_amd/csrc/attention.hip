@@ -48,6 +48,13 @@ __device__ __forceinline__ bf16x8 acc_to_bf16(const f32x16& a, int s2) {
     for (int j = 0; j < 8; ++j) f[j] = (bf16_t)a[8 * s2 + j];
     return f;
 }
+// max of a value with its partner 32 lanes away: one v_permlane32_swap (register file only) instead of a
+// shuffle through the LDS crossbar on the loop's serial chain
+__device__ __forceinline__ float max_across_halves(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+}
 // bit (key - kv0) set <=> key of this 64-key tile is padding (>= Tk) or masked; wave-uniform
 __device__ __forceinline__ uint64_t dead_keys(const uint8_t* mb, int kv0, int Tk, int lane) {
     const int key = kv0 + lane;
@@ -60,6 +67,9 @@ template <bool DROP>
 #endif
 #ifndef ATT_UNROLL
 #define ATT_UNROLL 1
+#endif
+#ifndef ATT_LAZY_LOG2
+#define ATT_LAZY_LOG2 8.0f
 #endif
 __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
                                                             long ldk, const bf16_t* __restrict__ V, long ldv,
@@ -92,6 +102,7 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
     for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
     float mrun = -INFINITY, lsum = 0.f;                       // running max (raw score units), partial row sum
     const float sc2 = scale * LOG2E;
+    const float lazy = ATT_LAZY_LOG2 / sc2;                   // in raw score units
     const int lc = t & 7, lr = t >> 3;                        // staging: chunk, row (+32)
     const bf16_t* Kb = K + (long)b * Tk * ldk + h * HD;
     const bf16_t* Vb = V + (long)b * Tk * ldv + h * HD;
@@ -162,8 +173,12 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
             float mx = sacc[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (__any(mx > mrun)) {                           // some row's maximum moved: rescale what is accumulated
+            mx = max_across_halves(mx);
+            // Lazy reference point: softmax does not care which constant is subtracted, so the accumulated sums are
+            // only rescaled when some row's maximum has risen by more than ATT_LAZY_LOG2 binades over its reference
+            // (probabilities then reach at most 2^ATT_LAZY_LOG2 before normalisation: nothing for fp32 sums or
+            // bf16's exponent range).  After the first few tiles this branch is rarely taken.
+            if (__any(mx > mrun + lazy)) {
                 const float mnew = fmaxf(mrun, mx);
                 const float alpha = mnew > mrun ? exp2f((mrun - mnew) * sc2) : 1.0f;
                 mrun = mnew;
