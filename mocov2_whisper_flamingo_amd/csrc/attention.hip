@@ -55,6 +55,11 @@ __device__ __forceinline__ float max_across_halves(float x) {
     const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
 }
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // bit (key - kv0) set <=> key of this 64-key tile is padding (>= Tk) or masked; wave-uniform
 __device__ __forceinline__ uint64_t dead_keys(const uint8_t* mb, int kv0, int Tk, int lane) {
     const int key = kv0 + lane;
@@ -67,6 +72,12 @@ template <bool DROP>
 #endif
 #ifndef ATT_UNROLL
 #define ATT_UNROLL 1
+#endif
+#ifndef ATT_PACKED
+#define ATT_PACKED 0
+#endif
+#ifndef ATT_MAX3
+#define ATT_MAX3 1
 #endif
 #ifndef ATT_LAZY_LOG2
 #define ATT_LAZY_LOG2 8.0f
@@ -170,9 +181,21 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
                 for (int i = 0; i < 16; ++i)
                     if ((i & 3) + 8 * (i >> 2) + 4 * hf > last) sacc[i] = -INFINITY;
             }
+#if ATT_MAX3
+            // MFMA results are never signalling NaNs: skip the canonicalising v_max the compiler puts before fmaxf
+            float mx = vmax3(sacc[0], sacc[1], sacc[2]);
+            float my = vmax3(sacc[3], sacc[4], sacc[5]);
+            mx = vmax3(mx, sacc[6], sacc[7]);
+            my = vmax3(my, sacc[8], sacc[9]);
+            mx = vmax3(mx, sacc[10], sacc[11]);
+            my = vmax3(my, sacc[12], sacc[13]);
+            mx = vmax3(mx, sacc[14], sacc[15]);
+            mx = vmax3(mx, my, my);
+#else
             float mx = sacc[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[i]);
+#endif
             mx = max_across_halves(mx);
             // Lazy reference point: softmax does not care which constant is subtracted, so the accumulated sums are
             // only rescaled when some row's maximum has risen by more than ATT_LAZY_LOG2 binades over its reference
@@ -187,6 +210,7 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
                 for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
             }
             const float msc = mrun == -INFINITY ? 0.f : mrun * sc2;
+#if ATT_PACKED
             const f32x2 sc2v = {sc2, sc2}, mscv = {-msc, -msc};
             f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
@@ -197,6 +221,16 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
                 ps2 += pv;
             }
             lsum += ps2[0] + ps2[1];                          // the normaliser is that of the un-dropped softmax
+#else
+            float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                sacc[i] = __builtin_amdgcn_exp2f(fmaf(sacc[i], sc2, -msc));
+                sacc[i + 1] = __builtin_amdgcn_exp2f(fmaf(sacc[i + 1], sc2, -msc));
+                ps0 += sacc[i]; ps1 += sacc[i + 1];
+            }
+            lsum += ps0 + ps1;
+#endif
             if (DROP) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
