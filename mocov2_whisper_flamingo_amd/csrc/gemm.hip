@@ -306,6 +306,12 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][B
 #define G_NST_SWITCH_TILES 1000
 #endif
 #define G_NUM_CU 256
+#ifndef G_BM160
+#define G_BM160 1
+#endif
+#ifndef G_BM160_NST
+#define G_BM160_NST 2
+#endif
 #ifndef G_SMALL_TILES
 #define G_SMALL_TILES 128
 #endif
@@ -758,6 +764,13 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
             return (double)M * tnn / ((double)rounds * G_NUM_CU * rows);
         };
         if (t96 >= G_T96_MIN_TILES && fill(t96, 96, p.M, tn) > G_FILL_RATIO * fill(t128, 128, p.M, tn)) bm = 96;
+#if G_BM160
+        // 160-row tiles where they save a whole round over 128-row ones (M = 12000, N = 768: 450 tiles in two rounds
+        // instead of 564 in three; double-buffered, two workgroups per CU: alone 88 -> 68 us at K = 3072, 35 -> 31 us at
+        // K = 768, and 1.2 % of the whole step with the other encoder's kernels filling the idle CUs either way)
+        const long t160 = ((p.M + 159) / 160) * tn;
+        if (bm == G_BM && t160 > G_NUM_CU && fill(t160, 160, p.M, tn) > G_FILL_RATIO * fill(t128, 128, p.M, tn)) bm = 160;
+#endif
     }
     // 256-row tiles (a wave owns 128 x 64: a quarter less LDS traffic per MFMA) pay off only where the tile
     // count stays far above the CU count: +8 % on 4096^3 and larger, a loss on every product of this network.
@@ -813,6 +826,8 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
             if (of) LAUNCHBM(64, 4, float, 64); else LAUNCHBM(64, 4, bf16_t, 64);
         } else if (bm == 256) {
             if (of) LAUNCHBM(128, 1, float, 256); else LAUNCHBM(128, 1, bf16_t, 256);
+        } else if (bm == 160) {
+            if (of) LAUNCHBM(128, G_BM160_NST, float, 160); else LAUNCHBM(128, G_BM160_NST, bf16_t, 160);
         } else if (bm == 96) {
             if (of) LAUNCHBM(128, 1, float, 96); else LAUNCHBM(128, 1, bf16_t, 96);
         } else if (!conv && bn == 128 && ntiles * g->batch <= G_DEEP_TILES) {     // at most one workgroup per CU: 3 K-steps in flight

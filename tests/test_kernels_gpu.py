@@ -32,8 +32,9 @@ def rnd(gen, *shape, dtype=torch.float32, scale=1.0):
 
 @pytest.mark.parametrize("M,N,K,odt", [(12000, 768, 768, torch.float32), (11990, 700, 264, torch.bfloat16),
                                        (12000, 768, 3072, torch.float32)])
-def test_gemm_row_tile_96(dev, M, N, K, odt):
-    """Shapes for which the host picks the 96-row tile (fills the last round of workgroups better): bias + GELU
+def test_gemm_row_tile_96_160(dev, M, N, K, odt):
+    """Shapes for which the host leaves the 128-row tile for one that fills the last round of workgroups better
+    (564 tiles of 128 rows -> 450 of 160; 96-row tiles from 1000 tiles on): bias + GELU
     (bf16 out) or bias + in-place fp32 residual, ragged M / N / K included."""
     g = torch.Generator().manual_seed(M + N + K)
     a, b = rnd(g, M, K, dtype=torch.bfloat16), rnd(g, N, K, dtype=torch.bfloat16, scale=0.05)
