@@ -441,6 +441,44 @@ __global__ __launch_bounds__(256) void avgpool_mask_kernel(const T* __restrict__
     }
 }
 
+// bf16 input, channel count a multiple of 8: 8 channels per thread as 16-byte loads, the HW positions unrolled four
+// deep (the scalar form above issued one dependent 2-byte load per position: 0.7 TB/s on the [600,16,2048] trunk output)
+template <typename TO>
+__global__ __launch_bounds__(256) void avgpool_mask_bf16x8_kernel(const bf16_t* __restrict__ x, TO* __restrict__ y,
+                                                                  const int64_t* __restrict__ lens, int Tn, int HW, int C8) {
+    const int frame = blockIdx.x;
+    const int cg = blockIdx.y * blockDim.x + threadIdx.x;
+    if (cg >= C8) return;
+    const int b = frame / Tn, t = frame - b * Tn;
+    const bool dead = lens && t >= lens[b];
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (!dead) {
+        const bf16_t* xp = x + ((long)frame * HW * C8 + cg) * 8;
+        const long step = (long)C8 * 8;
+        int p = 0;
+        for (; p + 4 <= HW; p += 4) {
+            bf16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const bf16x8*)(xp + (p + u) * step);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (float)v[u][e];
+        }
+        for (; p < HW; ++p) {
+            const bf16x8 v = *(const bf16x8*)(xp + p * step);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+        }
+    }
+    const float inv = 1.0f / (float)HW;
+    TO* yp = y + ((long)frame * C8 + cg) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) yp[e] = from_f32<TO>(s[e] * inv);
+}
+
 // Output rows per work item of the MFMA stem: the largest of 4, 2, 1 whose bf16 window fits in LDS twice per CU.
 static int stem_mfma_rows(int64_t W, size_t* lds_bytes) {
     for (int rows = 4; rows >= 1; rows >>= 1) {
@@ -564,6 +602,17 @@ extern "C" int avsr_avgpool_mask_fwd(avsr_stream_t stream, int in_dtype, int out
     if (!x || !y || B <= 0 || T <= 0 || HW <= 0 || C <= 0) return AVSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)(B * T)), block(256);
+    if (in_dtype == AVSR_BF16 && C % 8 == 0 && (uintptr_t)x % 16 == 0 && (out_dtype == AVSR_BF16 || out_dtype == AVSR_F32)) {
+        const int C8 = (int)(C / 8);
+        dim3 g8((unsigned)(B * T), (unsigned)((C8 + 255) / 256));
+        if (out_dtype == AVSR_BF16)
+            hipLaunchKernelGGL(avgpool_mask_bf16x8_kernel<bf16_t>, g8, block, 0, s, (const bf16_t*)x, (bf16_t*)y, lens, (int)T,
+                               (int)HW, C8);
+        else
+            hipLaunchKernelGGL(avgpool_mask_bf16x8_kernel<float>, g8, block, 0, s, (const bf16_t*)x, (float*)y, lens, (int)T,
+                               (int)HW, C8);
+        return avsr_launch_status();
+    }
 #define L(TI, TO) hipLaunchKernelGGL((avgpool_mask_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, (TO*)y, lens, (int)T, \
                                      (int)HW, (int)C)
     if (in_dtype == AVSR_F32 && out_dtype == AVSR_F32) L(float, float);
