@@ -99,12 +99,12 @@ def _free_port():
     return p
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, fused=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     m, sd = micro_model()
-    tr = FlatTrainer(m, bucket_mb=0.25, overlap=False)
+    tr = FlatTrainer(m, bucket_mb=0.25, overlap=False, fused_step=fused)
     full = synthetic_batch(B=2 * world, Tv=6, H=32, W=32, L=4, vocab=503, seed=3)
     mine = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
     _, _, _, _, grads, _ = oracle.training_step(sd, mine, 2, 2, masked_row="zero")
@@ -116,18 +116,22 @@ def _dp_worker(rank, world, port, q):
     tr.reduce_gradients()
     if rank == 0:
         _, _, _, _, ref, _ = oracle.training_step(sd, full, 2, 2, masked_row="zero")
-        worst = max(((params[k].grad - ref[k]).abs().max() / ref[k].abs().max().clamp_min(1e-6)).item() for k in ref)
+        # fused_step leaves the SUM over ranks in the buffer and hands the 1 / world to the optimizer kernels
+        mean = tr._pre_scale if fused else 1.0
+        assert mean == (1.0 / world if fused else 1.0)
+        worst = max(((params[k].grad * mean - ref[k]).abs().max() / ref[k].abs().max().clamp_min(1e-6)).item() for k in ref)
         q.put((worst, len(tr.buckets)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_dp_gradient_mean_over_gloo_equals_full_batch():
+@pytest.mark.parametrize("fused", [False, True])
+def test_dp_gradient_mean_over_gloo_equals_full_batch(fused):
     """N-rank averaged gradients == single-rank gradients on the concatenated batch (eval-mode BN)."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q, fused)) for r in range(world)]
     for p in procs:
         p.start()
     worst, nb = q.get(timeout=240)
