@@ -86,8 +86,10 @@ def cpu_baseline(whisper, threads, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # the first batch's encoders and the last batch's tail run un-overlapped inside the timed region (≈11 ms per
+    # run): 50 steps (0.4 s) keep that below 3 % of the figure
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
     ap.add_argument("--whisper", default="small")
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
