@@ -218,7 +218,8 @@ def main():
     final_loss = float(loss.item())
 
     roofline = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:
+        # every rank runs the extra step (it contains the gradient all-reduce); rank 0 reports
         ops.GEMM_PROFILE = []
         # per-launch durations of the kernel alone: nothing on a second stream sharing the CUs
         from mocov2_whisper_flamingo_amd import functional as Fn
