@@ -38,6 +38,24 @@ VOCAB = 51865
 PEAK_BF16_TFLOPS = 2500.0                      # dense MFMA peak, MI355X
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """File descriptor 1 points at stderr inside the block (native libraries included): stdout carries the one
+    JSON line and nothing else."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def synthetic_batch(B, T, H, W, seed, dev, L=32, mel_frames=3000):
     g = torch.Generator().manual_seed(seed)
     lens = torch.randint(T // 2 + 1, T + 1, (B,), generator=g)
@@ -134,12 +152,16 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-            if args.rehearse_backend == "nccl":
-                dist.init_process_group("nccl", device_id=dev)
-            else:
-                dist.init_process_group(args.rehearse_backend)
+            with _stdout_to_stderr():
+                if args.rehearse_backend == "nccl":
+                    dist.init_process_group("nccl", device_id=dev)
+                else:
+                    dist.init_process_group(args.rehearse_backend)
+                dist.barrier()
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            with _stdout_to_stderr():   # the collective library prints a version banner on stdout when a communicator is made
+                dist.init_process_group("nccl", device_id=dev)
+                dist.barrier()
 
     from mocov2_whisper_flamingo_amd import AVNet, ops
     from mocov2_whisper_flamingo_amd.dp import FlatTrainer
