@@ -22,14 +22,34 @@ static inline int avsr_launch_status() {
     return e == hipSuccess ? AVSR_OK : AVSR_EHIP;
 }
 
+// Butterfly reductions over the 64 lanes without the LDS crossbar: xor 1 / 2 by quad permutes, 8- and 16-lane sums by
+// the half-row and row mirrors (after the quad steps every quad is uniform, so a mirror pairs the right partners),
+// xor 16 / 32 by v_permlane16_swap / v_permlane32_swap.  Every lane ends with the full result.
+#define AVSR_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
+#define AVSR_WAVE_REDUCE(v, OP)                                                                             \
+    do {                                                                                                    \
+        v = OP(v, AVSR_DPP(v, 0xB1));  /* quad_perm [1,0,3,2] */                                            \
+        v = OP(v, AVSR_DPP(v, 0x4E));  /* quad_perm [2,3,0,1] */                                            \
+        v = OP(v, AVSR_DPP(v, 0x141)); /* row_half_mirror */                                                \
+        v = OP(v, AVSR_DPP(v, 0x140)); /* row_mirror */                                                     \
+        {                                                                                                   \
+            const unsigned u_ = __builtin_bit_cast(unsigned, v);                                            \
+            const auto s_ = __builtin_amdgcn_permlane16_swap(u_, u_, false, false);                         \
+            v = OP(__builtin_bit_cast(float, (unsigned)s_[0]), __builtin_bit_cast(float, (unsigned)s_[1])); \
+        }                                                                                                   \
+        {                                                                                                   \
+            const unsigned u_ = __builtin_bit_cast(unsigned, v);                                            \
+            const auto s_ = __builtin_amdgcn_permlane32_swap(u_, u_, false, false);                         \
+            v = OP(__builtin_bit_cast(float, (unsigned)s_[0]), __builtin_bit_cast(float, (unsigned)s_[1])); \
+        }                                                                                                   \
+    } while (0)
+__device__ __forceinline__ float avsr_addf(float a, float b) { return a + b; }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    AVSR_WAVE_REDUCE(v, avsr_addf);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    AVSR_WAVE_REDUCE(v, fmaxf);
     return v;
 }
 
