@@ -44,6 +44,30 @@ static inline int avsr_launch_status() {
         }                                                                                                   \
     } while (0)
 __device__ __forceinline__ float avsr_addf(float a, float b) { return a + b; }
+// sum over the 16 lanes of a row (lanes 16k .. 16k+15); every lane of the row gets it
+__device__ __forceinline__ float row16_sum(float v) {
+    v += AVSR_DPP(v, 0xB1);
+    v += AVSR_DPP(v, 0x4E);
+    v += AVSR_DPP(v, 0x141);
+    v += AVSR_DPP(v, 0x140);
+    return v;
+}
+// v + v[lane ^ O] for O = 8 (rotate the row by 8), 16 and 32 (lane-swap instructions): exact partners, no LDS
+template <int O> __device__ __forceinline__ float xor_add(float v) {
+    static_assert(O == 8 || O == 16 || O == 32, "xor_add: 8, 16 or 32");
+    if constexpr (O == 8) {
+        return v + AVSR_DPP(v, 0x128);                         // row_ror:8
+    } else {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        if constexpr (O == 16) {
+            const auto s = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+            return __builtin_bit_cast(float, (unsigned)s[0]) + __builtin_bit_cast(float, (unsigned)s[1]);
+        } else {
+            const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            return __builtin_bit_cast(float, (unsigned)s[0]) + __builtin_bit_cast(float, (unsigned)s[1]);
+        }
+    }
+}
 __device__ __forceinline__ float wave_sum(float v) {
     AVSR_WAVE_REDUCE(v, avsr_addf);
     return v;

@@ -129,8 +129,7 @@ __device__ __forceinline__ void stats_quad(const GemmP& p, f32x4 s, f32x4 s2, in
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float a = s[r], b = s2[r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        a = row16_sum(a); b = row16_sum(b);
         if ((lane & 15) == 0 && nb + r < p.N) {
             p.csum[(long)part * p.N + nb + r] = a;
             p.csq[(long)part * p.N + nb + r] = b;
@@ -242,8 +241,9 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
         // lanes with equal (lane % CG) own the same columns: fold them, then the 4 waves through LDS
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int o = CG; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+            if (CG <= 8) { s1[e] = xor_add<8>(s1[e]); s2[e] = xor_add<8>(s2[e]); }
+            s1[e] = xor_add<16>(s1[e]); s2[e] = xor_add<16>(s2[e]);
+            s1[e] = xor_add<32>(s1[e]); s2[e] = xor_add<32>(s2[e]);
         }
         if (lane < CG) {
 #pragma unroll

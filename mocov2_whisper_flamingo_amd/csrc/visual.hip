@@ -281,8 +281,7 @@ __global__ __launch_bounds__(256, 2) void stem3d_mfma_kernel(const float* __rest
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float a = s1[ct][r], c = s2[ct][r];
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+                    a = row16_sum(a); c = row16_sum(c);
                     if ((lane & 15) == 0) {
                         red[(wave * 2) * 64 + 16 * ct + 4 * q + r] = a;
                         red[(wave * 2 + 1) * 64 + 16 * ct + 4 * q + r] = c;
