@@ -166,6 +166,18 @@ int avsr_logmel_fwd(avsr_stream_t stream, int variant, int out_dtype, const floa
                     int64_t n_samples, int64_t n_valid, int64_t batch, const float* dft_table,
                     const float* mel_table, void* out, int64_t out_stride_b, int64_t out_stride_t,
                     int64_t out_stride_m, int64_t n_frames_out, float* workspace);
+/* avsr_logmel_fwd without a workspace argument, for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.
+ * The workspace is a fixed array of AVSR_LOGMEL_STATIC_FLOATS floats (8 MiB) inside the library's code object:
+ * every GPU the library runs on holds one copy until the process ends.  The call allocates nothing; it returns
+ * AVSR_EUNSUPPORTED when avsr_logmel_workspace_floats(batch, n_frames_out) exceeds AVSR_LOGMEL_STATIC_FLOATS
+ * (8 clips of 30 s fit).  All calls on one GPU share that GPU's array: calls that may overlap on one GPU (two
+ * streams, two threads) race - order them on one stream.  Results are bit-identical to avsr_logmel_fwd. */
+#define AVSR_LOGMEL_STATIC_FLOATS (2 * 1024 * 1024)
+int avsr_logmel_fwd_static(avsr_stream_t stream, int variant, int out_dtype, const float* wave, int64_t wave_stride,
+                           int64_t n_samples, int64_t n_valid, int64_t batch, const float* dft_table,
+                           const float* mel_table, void* out, int64_t out_stride_b, int64_t out_stride_t,
+                           int64_t out_stride_m, int64_t n_frames_out);
 /* Training-time form of the AVSR_MEL_SPEC_LN variant (datamodule/transforms.py:122-132): between the mel
  * bank and the clip layer norm it applies SpecAugment (transforms.py:144-179: per clip two frequency bands
  * of freq_width bins and two time bands of time_width frames set to zero; starts in freq_start / time_start,

@@ -21,6 +21,7 @@
 // of a bin in the same lane so the power needs no exchange.  Power goes to LDS
 // and is contracted with the (also fragment-packed) mel bank.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -354,10 +355,11 @@ extern "C" int64_t avsr_logmel_workspace_floats(int64_t batch, int64_t n_frames_
     return batch * n_frames_out * LM_NMEL + batch * lm_nblk((int)n_frames_out) * 2;
 }
 
-extern "C" int avsr_logmel_fwd(avsr_stream_t stream, int variant, int out_dtype, const float* wave,
-                               int64_t wave_stride, int64_t n_samples, int64_t n_valid, int64_t batch,
-                               const float* dft_table, const float* mel_table, void* out, int64_t out_stride_b,
-                               int64_t out_stride_t, int64_t out_stride_m, int64_t n_frames_out, float* workspace) {
+namespace {
+int logmel_fwd_impl(avsr_stream_t stream, int variant, int out_dtype, const float* wave,
+                    int64_t wave_stride, int64_t n_samples, int64_t n_valid, int64_t batch,
+                    const float* dft_table, const float* mel_table, void* out, int64_t out_stride_b,
+                    int64_t out_stride_t, int64_t out_stride_m, int64_t n_frames_out, float* workspace) {
     if (!wave || !dft_table || !mel_table || !out || !workspace) return AVSR_EINVAL;
     if (batch <= 0 || n_frames_out <= 0 || n_valid < 0 || n_valid > n_samples || wave_stride < n_valid)
         return AVSR_EINVAL;
@@ -400,6 +402,55 @@ extern "C" int avsr_logmel_fwd(avsr_stream_t stream, int variant, int out_dtype,
                                (long)out_stride_m);
     }
     return avsr_launch_status();
+}
+
+// Scratch of avsr_logmel_fwd_static: one copy per GPU, held from the moment the code object is loaded on that GPU
+// until the process ends.  In host code the array's name is only a handle for hipGetSymbolAddress - the kernels
+// get the per-device address that call returns.
+__device__ __align__(256) float scratch[AVSR_LOGMEL_STATIC_FLOATS];
+constexpr int LM_MAX_DEVICES = 64;
+std::mutex scratch_mutex;
+float* scratch_ptr[LM_MAX_DEVICES] = {};
+
+// address of the current device's copy of `scratch` (looked up once per device), or nullptr
+float* logmel_static_scratch() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LM_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (!scratch_ptr[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        scratch_ptr[dev] = (float*)p;
+    }
+    return scratch_ptr[dev];
+}
+}  // namespace
+
+extern "C" int avsr_logmel_fwd(avsr_stream_t stream, int variant, int out_dtype, const float* wave,
+                               int64_t wave_stride, int64_t n_samples, int64_t n_valid, int64_t batch,
+                               const float* dft_table, const float* mel_table, void* out, int64_t out_stride_b,
+                               int64_t out_stride_t, int64_t out_stride_m, int64_t n_frames_out, float* workspace) {
+    return logmel_fwd_impl(stream, variant, out_dtype, wave, wave_stride, n_samples, n_valid, batch, dft_table,
+                           mel_table, out, out_stride_b, out_stride_t, out_stride_m, n_frames_out, workspace);
+}
+
+extern "C" int avsr_logmel_fwd_static(avsr_stream_t stream, int variant, int out_dtype, const float* wave,
+                                      int64_t wave_stride, int64_t n_samples, int64_t n_valid, int64_t batch,
+                                      const float* dft_table, const float* mel_table, void* out,
+                                      int64_t out_stride_b, int64_t out_stride_t, int64_t out_stride_m,
+                                      int64_t n_frames_out) {
+    if (batch <= 0 || n_frames_out <= 0) return AVSR_EINVAL;
+    if (batch > 65535 || n_frames_out > AVSR_LOGMEL_STATIC_FLOATS) return AVSR_EUNSUPPORTED;
+    if (avsr_logmel_workspace_floats(batch, n_frames_out) > AVSR_LOGMEL_STATIC_FLOATS) return AVSR_EUNSUPPORTED;
+    float* ws = logmel_static_scratch();
+    if (!ws) return AVSR_EHIP;
+    // every word of the workspace the finalize kernel reads is written by the first kernel of the same call,
+    // so nothing of the previous call's contents has to be cleared
+    return logmel_fwd_impl(stream, variant, out_dtype, wave, wave_stride, n_samples, n_valid, batch, dft_table,
+                           mel_table, out, out_stride_b, out_stride_t, out_stride_m, n_frames_out, ws);
 }
 
 extern "C" int64_t avsr_logmel_augment_workspace_floats(int64_t batch, int64_t n_frames_out) {

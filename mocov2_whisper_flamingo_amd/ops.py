@@ -277,9 +277,11 @@ def logmel_tables(variant, device):
     return dft, mel
 
 
-def logmel_fwd(wave, tables, variant, *, n_samples=None, n_frames=None, out_dtype=torch.float32, channels_last=False):
+def logmel_fwd(wave, tables, variant, *, n_samples=None, n_frames=None, out_dtype=torch.float32, channels_last=False,
+               out=None, static_workspace=False):
     """wave [B, n_valid] fp32 (read as zero-padded to ``n_samples``) -> mel features [B,80,n_frames], or
-    [B,n_frames,80] with ``channels_last``."""
+    [B,n_frames,80] with ``channels_last``.  ``static_workspace``: use the library's fixed per-GPU scratch array
+    instead of allocating a workspace (with a caller-provided ``out`` the call allocates nothing)."""
     lib = _lib.load()
     _need_cuda(wave, *tables)
     if wave.dim() != 2 or wave.dtype != torch.float32 or wave.stride(1) != 1:
@@ -289,8 +291,16 @@ def logmel_fwd(wave, tables, variant, *, n_samples=None, n_frames=None, out_dtyp
     if n_frames is None:
         n_frames = n_samples // 160 if variant == MEL_WHISPER else 3000
     shape = (B, n_frames, 80) if channels_last else (B, 80, n_frames)
-    out = torch.empty(shape, dtype=out_dtype, device=wave.device)
+    if out is None:
+        out = torch.empty(shape, dtype=out_dtype, device=wave.device)
+    elif tuple(out.shape) != shape or out.dtype != out_dtype or not out.is_contiguous() or not out.is_cuda:
+        raise ValueError("out must be a contiguous GPU tensor of the result's shape and dtype")
     st, sm = (80, 1) if channels_last else (1, n_frames)
+    if static_workspace:
+        check(lib.avsr_logmel_fwd_static(_stream(), variant, _DT[out_dtype], wave.data_ptr(), wave.stride(0), n_samples,
+                                         n_valid, B, tables[0].data_ptr(), tables[1].data_ptr(), out.data_ptr(),
+                                         80 * n_frames, st, sm, n_frames), "avsr_logmel_fwd_static")
+        return out
     ws = torch.empty(int(lib.avsr_logmel_workspace_floats(B, n_frames)), dtype=torch.float32, device=wave.device)
     check(lib.avsr_logmel_fwd(_stream(), variant, _DT[out_dtype], wave.data_ptr(), wave.stride(0), n_samples, n_valid, B,
                               tables[0].data_ptr(), tables[1].data_ptr(), out.data_ptr(), 80 * n_frames, st, sm,

@@ -1,0 +1,37 @@
+"""The entry point that allocates nothing (avsr_logmel_fwd_static): same results as avsr_logmel_fwd, bit for bit,
+on two calls in a row that share the per-GPU scratch array, the second with a smaller input."""
+import pytest
+import torch
+
+from mocov2_whisper_flamingo_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant", [ops.MEL_WHISPER, ops.MEL_SPEC_LN])
+def test_logmel_static_matches_workspace_entry(variant):
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    tables = ops.logmel_tables(variant, dev)
+    g = torch.Generator().manual_seed(5)
+    # first call: 4 clips of 30 s; second call: 2 clips of 7.3 s (fewer workgroups, fewer frames: most of the
+    # scratch keeps the first call's values)
+    for B, n, n_frames in ((4, 480000, 3000), (2, 116800, 730)):
+        wave = (0.1 * torch.randn(B, n, generator=g)).to(dev)
+        ref = ops.logmel_fwd(wave, tables, variant, n_frames=n_frames, channels_last=True)
+        out = torch.full((B, n_frames, 80), float("nan"), device=dev)
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_stats(dev)["allocation.all.allocated"]
+        got = ops.logmel_fwd(wave, tables, variant, n_frames=n_frames, channels_last=True, out=out,
+                             static_workspace=True)
+        after = torch.cuda.memory_stats(dev)["allocation.all.allocated"]
+        assert after == before, "the static entry point must not allocate"
+        assert got.data_ptr() == out.data_ptr()
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, ref)
+    # a workspace beyond the fixed array is rejected with a clear error, not truncated
+    B, n_frames = 16, 3000
+    assert lib.avsr_logmel_workspace_floats(B, n_frames) > 2 * 1024 * 1024
+    wave = torch.zeros(B, 480000, device=dev)
+    with pytest.raises(_lib.AvsrHipError, match="unsupported"):
+        ops.logmel_fwd(wave, tables, variant, n_frames=n_frames, channels_last=True, static_workspace=True)
