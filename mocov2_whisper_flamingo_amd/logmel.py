@@ -8,7 +8,8 @@ a waveform of up to 30 s is read as zero-padded to 480 000 samples and becomes
 torchaudio's ``MelSpectrogram`` -> pad/trim to 3000 frames -> whole-clip layer norm,
 returned as ``[B, 3000, 80]`` like the pipeline's transpose does;
 ``LogMelFrontend("melspec_norm").train(...)`` is its training pipeline
-(transforms.py:122-132): SpecAugment bands and babble noise at a random SNR between
+(transforms.py:122-132): SpecAugment bands (48 frames / 10 mel bins, as the reference applies
+them to the [80, frames] tensor) and babble noise at a random SNR between
 the mel bank and the layer norm, with the random draws made on the host as the
 reference does.
 """
@@ -54,22 +55,30 @@ class LogMelFrontend:
 
     SNR_LEVELS = (-5, 0, 5, 10, 15, 20, 999999)          # transforms.py:50
 
+    BIN_BAND = 80 // 8           # transforms.py:167 on the [80, frames] tensor: size(0) // 8 mel bins
+    FRAME_BAND = 48              # transforms.py:152,164 on the same tensor: 48 of its columns = frames
+
     def draw(self, batch, n_samples, noise_len, rng=random):
-        """The random choices of one training batch, drawn as transforms.py:55-57,163,176 draw them: two
-        frequency-band starts in [0, 80-48), two time-band starts in [0, frames - frames//8) over the un-padded
-        frame count, a start offset into the noise recording and an SNR level per clip."""
+        """The random choices of one training batch, in the reference's order per clip.  SpecAugment runs on the
+        [80, frames] mel (transforms.py:127, before the transpose at :129), so its first loop (:157-164) draws two
+        starts in [0, frames - 48) for bands of 48 frames and its second (:171-177) two starts in [0, 80 - 10)
+        for bands of 10 mel bins, over the un-padded frame count; then AddNoise draws a start offset into the
+        noise recording and an SNR level (:55-57).  Returns (bin_starts, frame_starts, offsets, snr)."""
         frames = 1 + n_samples // 160
-        tw = frames // 8
-        fs = [[rng.randrange(0, 80 - 48) for _ in range(2)] for _ in range(batch)]
-        ts = [[rng.randrange(0, frames - tw) if frames - tw > 0 else -1 for _ in range(2)] for _ in range(batch)]
-        off = [rng.randint(0, noise_len - self.N_FRAMES) for _ in range(batch)]
-        snr = [float(rng.choice(self.SNR_LEVELS)) for _ in range(batch)]
+        fs, ts, off, snr = [], [], [], []
+        for _ in range(batch):
+            room = frames - self.FRAME_BAND
+            ts.append([rng.randrange(0, room) if room > 0 else -1 for _ in range(2)])
+            fs.append([rng.randrange(0, 80 - self.BIN_BAND) for _ in range(2)])
+            off.append(rng.randint(0, noise_len - self.N_FRAMES))
+            snr.append(float(rng.choice(self.SNR_LEVELS)))
         return fs, ts, off, snr
 
     def train(self, wave, noise_recording, *, draws=None, rng=random, dtype=torch.float32, channels_last=True):
         """wave [B, n] fp32 on the GPU, ``noise_recording`` a 1-D fp32 GPU tensor of at least 3000 values (the
         reference slices 3000 consecutive samples of babble_noise.wav and adds them to the mel rows).
-        ``draws`` = (freq_starts, time_starts, noise_offsets, snr_db) overrides the random choices."""
+        ``draws`` = (mel-bin band starts, frame band starts, noise_offsets, snr_db) overrides the random
+        choices."""
         if self.code != ops.MEL_SPEC_LN:
             raise ValueError('the training pipeline belongs to the "melspec_norm" variant')
         B, n = wave.shape
@@ -80,4 +89,5 @@ class LogMelFrontend:
                                       snr_db=torch.tensor(snr, dtype=torch.float32, device=dev),
                                       freq_start=torch.tensor(fs, dtype=torch.int32, device=dev),
                                       time_start=torch.tensor(ts, dtype=torch.int32, device=dev),
+                                      freq_width=self.BIN_BAND, time_width=self.FRAME_BAND,
                                       n_frames=self.N_FRAMES, out_dtype=dtype, channels_last=channels_last)

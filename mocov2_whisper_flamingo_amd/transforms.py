@@ -20,16 +20,19 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 
 def adaptive_time_mask(length, window=10, stride=25, rng=random):
     """Frames ``AdaptiveTimeMask(window, stride)`` zeroes (datamodule/transforms.py:27-45), as a list of
-    booleans.  One candidate mask per started ``stride`` frames; each draws a pair (t, t_end) below ``window``,
-    a start below ``length - t``, and zeroes ``t_end`` frames from it (the reference uses the second draw for the
-    mask length and skips the mask when the first is 0)."""
+    booleans.  One candidate mask per started ``stride`` frames.  All (t, t_end) pairs are drawn first, below
+    ``window`` (:36); then, in order, each candidate with ``length - t > 0`` draws a start below ``length - t``
+    (:40) and only after that draw is skipped when ``t`` is 0 (:41-42); otherwise ``t_end`` frames from the
+    start are zeroed (:43-44: the second draw is the mask length)."""
     zero = [False] * length
     n_mask = int((length + stride - 0.1) // stride)
     pairs = [(rng.randrange(0, window), rng.randrange(0, window)) for _ in range(n_mask)]
     for t, t_len in pairs:
-        if length - t <= 0 or t == 0:
+        if length - t <= 0:
             continue
         t_start = rng.randrange(0, length - t)
+        if t == 0:
+            continue
         for i in range(t_start, min(t_start + t_len, length)):
             zero[i] = True
     return zero

@@ -97,18 +97,23 @@ def torchaudio_melspec_norm(wave, target_len=3000):
     return torch.stack([F.layer_norm(xi, xi.shape, eps=1e-8) for xi in x])
 
 
-def spec_augment(mel_tf, freq_starts, time_starts, freq_width=48):
-    """``AudioTransform._apply_spec_augment`` (transforms.py:144-179) on one [frames, 80] clip, with the random
-    band starts passed in (negative = band skipped): two frequency bands of 48 bins and two time bands of
-    frames // 8 frames are zeroed."""
-    x = mel_tf.clone()
-    for f0 in freq_starts:
-        if f0 >= 0 and x.shape[1] - freq_width > 0:
-            x[:, f0:f0 + freq_width] = 0
-    tw = x.shape[0] // 8
-    for t0 in time_starts:
-        if t0 >= 0 and x.shape[0] - tw > 0:
-            x[t0:t0 + tw, :] = 0
+def spec_augment(mel_ft, frame_starts, bin_starts, frame_width=48):
+    """``AudioTransform._apply_spec_augment`` as the reference EXECUTES it.  The pipeline calls it at
+    transforms.py:127 on the MelSpectrogram output [80, frames]; the transpose to [frames, 80] only comes two
+    steps later (:129).  The function indexes that tensor as (time x frequency), so on the [80, frames] tensor
+    its "freq" loop (:152-164: width 48, start in [0, size(1) - 48), columns ``[:, s:s+48]``) zeroes two bands of
+    48 FRAMES, and its "time" loop (:167-177: width size(0) // 8 = 10, start in [0, 80 - 10), rows
+    ``[s:s+10, :]``) zeroes two bands of 10 MEL BINS - both before pad/trim (:128).  ``frame_starts`` /
+    ``bin_starts`` are the random starts, in that order of drawing (negative = band skipped)."""
+    x = mel_ft.clone()
+    n_bins, frames = x.shape
+    for s0 in frame_starts:
+        if s0 >= 0 and frames - frame_width > 0:
+            x[:, s0:s0 + frame_width] = 0
+    bw = n_bins // 8
+    for s0 in bin_starts:
+        if s0 >= 0 and n_bins - bw > 0:
+            x[s0:s0 + bw, :] = 0
     return x
 
 
@@ -122,15 +127,16 @@ def add_noise(waveform, noise, snr_db):
     return waveform + scale.unsqueeze(-1) * noise
 
 
-def torchaudio_melspec_train(wave, freq_starts, time_starts, noise_segments, snr_db, target_len=3000):
+def torchaudio_melspec_train(wave, bin_starts, frame_starts, noise_segments, snr_db, target_len=3000):
     """``AudioTransform`` training pipeline (transforms.py:122-132), one clip per row, with the random draws
-    given: MelSpectrogram -> SpecAugment on [frames, 80] -> pad/trim to 3000 frames -> AddNoise on the [80, 3000]
-    view (transforms.py:53-59: the mel rows are treated as audio channels) -> whole-clip layer norm."""
+    given: MelSpectrogram -> SpecAugment on the [80, frames] tensor (see ``spec_augment``) -> pad/trim to 3000
+    frames -> transpose -> AddNoise (transforms.py:53-59 transposes back: the mel rows are treated as audio
+    channels) -> whole-clip layer norm."""
     mag = power_stft(wave)
     mel = (mag.transpose(1, 2) @ mel_filters_htk()).transpose(1, 2)       # [B,80,frames]
     out = []
     for b in range(mel.shape[0]):
-        x = spec_augment(mel[b].t(), freq_starts[b], time_starts[b]).t()  # [80, frames]
+        x = spec_augment(mel[b], frame_starts[b], bin_starts[b])         # [80, frames]
         t = x.shape[-1]
         x = F.pad(x, (0, target_len - t)) if t < target_len else x[..., :target_len]
         x = add_noise(x, noise_segments[b].view(1, -1), torch.tensor([float(snr_db[b])]))

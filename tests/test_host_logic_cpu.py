@@ -143,7 +143,8 @@ def test_dp_gradient_mean_over_gloo_equals_full_batch(fused):
 
 def test_adaptive_time_mask_draws_like_the_reference():
     """Host-side draw of AdaptiveTimeMask (datamodule/transforms.py:27-45): one candidate per started 25 frames,
-    mask lengths below the window, nothing outside the clip; a zero first draw skips the mask."""
+    mask lengths below the window, nothing outside the clip; a zero first draw skips the mask after its start
+    has been drawn."""
     import random
     from mocov2_whisper_flamingo_amd.transforms import adaptive_time_mask
 
@@ -156,9 +157,42 @@ def test_adaptive_time_mask_draws_like_the_reference():
             assert a <= v < b
             return v
 
-    # length 75 -> int((75 + 25 - 0.1) // 25) = 3 candidates; pairs (t, len): (4, 6), (0, 9) skipped, (9, 3)
-    z = adaptive_time_mask(75, 10, 25, Fixed([4, 6, 0, 9, 9, 3, 70, 10]))
+    # length 75 -> int((75 + 25 - 0.1) // 25) = 3 candidates; pairs (t, len): (4, 6), (0, 9), (9, 3).  The pair with
+    # t = 0 still draws its start (33, transforms.py:40) before it is skipped (:41-42)
+    z = adaptive_time_mask(75, 10, 25, Fixed([4, 6, 0, 9, 9, 3, 70, 33, 10]))
     assert [i for i, v in enumerate(z) if v] == [10, 11, 12, 70, 71, 72, 73, 74]
     for seed in range(20):
         z = adaptive_time_mask(60, 10, 25, random.Random(seed))
         assert len(z) == 60 and sum(z) <= 3 * 9
+
+
+def test_spec_augment_draws_follow_the_reference_order_and_ranges():
+    """LogMelFrontend.draw without a GPU: per clip two frame-band starts in [0, frames - 48) are drawn first, then
+    two mel-bin band starts in [0, 70), then the noise offset and the SNR level (datamodule/transforms.py:157-177
+    on the [80, frames] tensor of :127, then :55-57)."""
+    from mocov2_whisper_flamingo_amd.logmel import LogMelFrontend
+
+    class Recorder:
+        def __init__(self):
+            self.calls = []
+
+        def randrange(self, a, b):
+            self.calls.append(("randrange", a, b))
+            return b - 1
+
+        def randint(self, a, b):
+            self.calls.append(("randint", a, b))
+            return b
+
+        def choice(self, seq):
+            self.calls.append(("choice", len(seq)))
+            return seq[-1]
+
+    fe = LogMelFrontend.__new__(LogMelFrontend)          # draw() needs no device state
+    rec = Recorder()
+    fs, ts, off, snr = fe.draw(2, 480000, 20000, rec)
+    per_clip = [("randrange", 0, 3001 - 48)] * 2 + [("randrange", 0, 70)] * 2 + [("randint", 0, 17000), ("choice", 7)]
+    assert rec.calls == per_clip * 2
+    assert ts == [[2952, 2952]] * 2 and fs == [[69, 69]] * 2 and off == [17000] * 2 and snr == [999999.0] * 2
+    fs, ts, _, _ = fe.draw(1, 160 * 40, 20000, Recorder())        # 41 frames: no room for a 48-frame band
+    assert ts == [[-1, -1]] and fs == [[69, 69]]

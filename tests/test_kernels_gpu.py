@@ -618,16 +618,18 @@ def test_melspec_layernorm_matches_oracle(dev):
 def test_melspec_training_pipeline_matches_oracle(dev):
     """Training-time pipeline (SpecAugment bands + noise at a target SNR per mel row + clip layer norm) with fixed
     draws against the CPU restatement.  PARITY UNPINNED like the evaluation variant (torchaudio absent): the
-    add_noise arithmetic follows torchaudio's documented formula.  Covers overlapping / skipped bands, the
-    'clean' SNR level 999999, a 10 s clip (frames // 8 = 125) and a band reaching the trimmed last frame."""
+    add_noise arithmetic follows torchaudio's documented formula.  Bands as the reference applies them to its
+    [80, frames] tensor (datamodule/transforms.py:127,152-177): 48 frames and 10 mel bins.  Covers overlapping /
+    skipped bands, the 'clean' SNR level 999999, a 10 s clip and a band reaching the trimmed last frame."""
     import random
     from mocov2_whisper_flamingo_amd import LogMelFrontend
     fe = LogMelFrontend("melspec_norm", dev)
     g = torch.Generator().manual_seed(12)
     noise_rec = 0.3 * torch.randn(20000, generator=g)
+    # fs = starts of the 10-bin mel bands in [0, 70), ts = starts of the 48-frame bands in [0, frames - 48)
     for n, fs, ts, off, snr in (
-            (480000, [[0, 31], [10, 20], [-1, 5]], [[0, 2626], [100, 300], [-1, -1]], [0, 17000, 5], [-5.0, 999999.0, 10.0]),
-            (160000, [[3, 3], [31, 0], [7, -1]], [[0, 875], [400, 500], [10, -1]], [100, 200, 300], [0.0, 20.0, 15.0])):
+            (480000, [[0, 69], [10, 15], [-1, 5]], [[0, 2952], [100, 130], [-1, -1]], [0, 17000, 5], [-5.0, 999999.0, 10.0]),
+            (160000, [[3, 3], [69, 0], [7, -1]], [[0, 952], [400, 500], [10, -1]], [100, 200, 300], [0.0, 20.0, 15.0])):
         wave = _seeded_wave(n, 8, batch=3)
         wave[2] *= 0.05
         segs = [noise_rec[o:o + 3000] for o in off]
@@ -641,7 +643,7 @@ def test_melspec_training_pipeline_matches_oracle(dev):
         assert (got16.float().cpu() - ref.transpose(1, 2)).abs().max() < 2e-2 * max(1.0, float(ref.abs().max()))
     # the host-side draws stay in the reference's ranges
     fs, ts, off, snr = fe.draw(64, 480000, 20000, random.Random(1))
-    assert all(0 <= f < 32 for r in fs for f in r) and all(0 <= t < 3001 - 375 for r in ts for t in r)
+    assert all(0 <= f < 70 for r in fs for f in r) and all(0 <= t < 3001 - 48 for r in ts for t in r)
     assert all(0 <= o <= 17000 for o in off) and set(snr) <= set(map(float, fe.SNR_LEVELS))
     out = fe.train(_seeded_wave(480000, 9, batch=2).to(dev), noise_rec.to(dev), rng=random.Random(2))
     assert torch.isfinite(out).all() and abs(float(out[0].mean())) < 1e-3

@@ -189,7 +189,8 @@ def test_all_keys_masked_policy():
 def test_add_noise_reaches_the_requested_snr_and_spec_augment_bands():
     """The restated torchaudio add_noise (unpinned: torchaudio absent) has the property its documentation states:
     after scaling, 10 log10(E_signal / E_added_noise) equals the requested SNR for every row; an all-zero row
-    gets no noise.  SpecAugment zeroes exactly the drawn bands (transforms.py:144-179)."""
+    gets no noise.  SpecAugment zeroes exactly the regions the reference's code zeroes on the tensor it is
+    handed (transforms.py:125-129,144-179)."""
     from oracle.ref_logmel import add_noise, spec_augment
     g = torch.Generator().manual_seed(1)
     x = torch.rand(5, 3000, generator=g) * torch.tensor([1.0, 10.0, 0.1, 3.0, 0.0]).view(5, 1)
@@ -201,7 +202,14 @@ def test_add_noise_reaches_the_requested_snr_and_spec_augment_bands():
         assert (got - snr).abs().max() < 1e-3
         assert added[4].abs().max() == 0
     assert (add_noise(x, n, torch.tensor([999999.0])) - x).abs().max() == 0
-    mel = torch.ones(3001, 80)
-    out = spec_augment(mel, [3, -1], [100, 2626])
-    assert out[:, 3:51].abs().max() == 0 and out[100:475].abs().max() == 0 and out[2626:3001].abs().max() == 0
-    assert out.sum() == (3001 - 750) * (80 - 48)
+    # the reference runs SpecAugment on the [80, frames] tensor (transforms.py:127, transposed only at :129):
+    # its first loop zeroes 48 COLUMNS = frames (:164), its second 80 // 8 = 10 ROWS = mel bins (:167,177)
+    mel = torch.ones(80, 3001)
+    out = spec_augment(mel, [100, 2952], [3, -1])
+    zeroed = out == 0
+    assert zeroed[:, 100:148].all() and zeroed[:, 2952:3000].all() and zeroed[3:13, :].all()
+    assert int(zeroed.sum()) == 10 * 3001 + 70 * 96
+    assert not zeroed[13:, 148:2952].any() and not zeroed[:3, :100].any() and not zeroed[20, 3000]
+    # 48 frames or fewer: the frame bands are skipped (:160-162), the mel-bin bands are not
+    short = spec_augment(torch.ones(80, 48), [0, 0], [69, 0])
+    assert int((short == 0).sum()) == 20 * 48 and (short[69:79] == 0).all() and (short[:10] == 0).all()
