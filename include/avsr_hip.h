@@ -181,7 +181,9 @@ int avsr_logmel_fwd_static(avsr_stream_t stream, int variant, int out_dtype, con
 /* Training-time form of the AVSR_MEL_SPEC_LN variant (datamodule/transforms.py:122-132): between the mel
  * bank and the clip layer norm it applies SpecAugment (transforms.py:144-179: per clip two frequency bands
  * of freq_width bins and two time bands of time_width frames set to zero; starts in freq_start / time_start,
- * device int32 [batch,2], a negative start = band not drawn, either pointer may be NULL) and AddNoise
+ * device int32 [batch,2], a negative start = band not drawn, either pointer may be NULL; the reference calls the
+ * function on the [80, frames] tensor, transforms.py:127 before the transpose at :129, which makes its bands
+ * freq_width = 80/8 = 10 mel bins and time_width = 48 frames) and AddNoise
  * (transforms.py:47-59 with torchaudio.functional.add_noise: mel row m += sqrt(E_m / E_noise) * 10^(-snr/20)
  * * noise, E = sum of squares over the frames; noise: fp32, n_frames_out values per clip at
  * noise + clip * noise_stride (stride 0 = one segment for all clips); snr_db: device fp32 [batch]).
@@ -305,6 +307,10 @@ int avsr_sum_parts(avsr_stream_t stream, int out_dtype, const float* parts, int6
                    const float* bias, int64_t ncol, void* out, int64_t n);
 /* out = a + b + c (c may be NULL)  (models/av_net.py:106) */
 int avsr_add3(avsr_stream_t stream, int dtype, const void* a, const void* b, const void* c, void* out, int64_t n);
+/* out[i] = x[i] + table[i % period]: PositionalEncoding.forward (models/utils.py:21-28) called on its own, x + pe[:, :T]
+ * for x [B,T,d] with table = the fp32 [T,d] slice of the sinusoid buffer and period = T*d */
+int avsr_add_table(avsr_stream_t stream, int dtype, const void* x, const float* table, void* out, int64_t n,
+                   int64_t period);
 /* Whisper decoder input (hf modeling_whisper.py:649-797: embed_tokens(ids) * embed_scale +
  * embed_positions.weight[past : past + T]): out[row, :] = table[ids[row], :] * scale + pos[past + row % T, :],
  * fp32 [rows, D] with rows = batch * T.  table: [V, D] fp32 or bf16; pos: fp32 [n_pos, D]; past + T <= n_pos.

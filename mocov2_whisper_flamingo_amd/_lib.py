@@ -78,6 +78,7 @@ SIGNATURES = {
     "avsr_sum_parts": (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _i64, _vp, _i64]),
     "avsr_cast_rows": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _i64, _i64, _f32]),
     "avsr_add3": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64]),
+    "avsr_add_table": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _i64]),
     "avsr_embed_tokens": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp]),
     "avsr_sumsq_accumulate": (_i32, [_vp, _vp, _i64, _vp]),
     "avsr_clip_scale": (_i32, [_vp, _vp, _f32, _f32, _vp, _vp]),

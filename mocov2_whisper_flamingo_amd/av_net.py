@@ -74,9 +74,10 @@ class AVNet(nn.Module):
         self.fusion_scalar = nn.Parameter(torch.tensor([1.0]))  # present in checkpoints, unused in forward
         self.pos_enc_audio = PositionalEncoding(d_model, enable_logging=enable_logging)
         self.pos_enc_video = PositionalEncoding(d_model, enable_logging=enable_logging)
-        self.decoder = Decoder(d_model=d_model, vocab_size=vocab_size, enable_logging=enable_logging)
+        self.decoder = Decoder(d_model=d_model, vocab_size=vocab_size, enable_logging=enable_logging, dtype=dtype)
 
         self._cache = Fn.WeightCache(dtype)
+        self.decoder._cache = self._cache
         self._seed, self._step = int(seed), 0
         self.overlap_encoders = True        # run the visual frontend on a second stream next to the audio encoder
         self._side = None

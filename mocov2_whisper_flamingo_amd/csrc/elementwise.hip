@@ -138,6 +138,15 @@ __global__ __launch_bounds__(256) void add3_kernel(const T* __restrict__ a, cons
         out[i] = from_f32<T>(to_f32<T>(a[i]) + to_f32<T>(b[i]) + (c ? to_f32<T>(c[i]) : 0.f));
 }
 
+// out[i] = x[i] + table[i % period]: a [T, d] fp32 table added to every batch item (models/utils.py:25)
+template <typename T>
+__global__ __launch_bounds__(256) void add_table_kernel(const T* __restrict__ x, const float* __restrict__ table,
+                                                        T* __restrict__ out, long n, long period) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = from_f32<T>(to_f32<T>(x[i]) + table[i % period]);
+}
+
 // out[i] = sum_s parts[s][i] (+ bias[i % ncol]); combines split-K partial products
 template <typename TO>
 __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ parts, long part_stride, int S,
@@ -376,6 +385,17 @@ extern "C" int avsr_add3(avsr_stream_t stream, int dtype, const void* a, const v
     dim3 grid(grid_for(n, 256, 4096)), block(256);
     if (dtype == AVSR_F32) hipLaunchKernelGGL(add3_kernel<float>, grid, block, 0, s, (const float*)a, (const float*)b, (const float*)c, (float*)out, (long)n);
     else if (dtype == AVSR_BF16) hipLaunchKernelGGL(add3_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c, (bf16_t*)out, (long)n);
+    else return AVSR_EINVAL;
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_add_table(avsr_stream_t stream, int dtype, const void* x, const float* table, void* out, int64_t n,
+                              int64_t period) {
+    if (!x || !table || !out || n <= 0 || period <= 0) return AVSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(grid_for(n, 256, 4096)), block(256);
+    if (dtype == AVSR_F32) hipLaunchKernelGGL(add_table_kernel<float>, grid, block, 0, s, (const float*)x, table, (float*)out, (long)n, (long)period);
+    else if (dtype == AVSR_BF16) hipLaunchKernelGGL(add_table_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, table, (bf16_t*)out, (long)n, (long)period);
     else return AVSR_EINVAL;
     return avsr_launch_status();
 }

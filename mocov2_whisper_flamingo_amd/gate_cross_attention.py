@@ -51,6 +51,8 @@ class GatedCrossAttentionBlock(nn.Module):
             raise ValueError("attention kernels are built for head_dim 64")
         p = self.p_drop if self.training else 0.0
         cache = self._cache
+        if cache is None or cache.dtype != x.dtype:        # stand-alone block: its own weight copies in x's dtype
+            cache = self._cache = Fn.WeightCache(x.dtype)
         x2 = x.reshape(B * T, d)
         if xa is not None:
             Tk = xa.shape[1]

@@ -308,12 +308,13 @@ def logmel_fwd(wave, tables, variant, *, n_samples=None, n_frames=None, out_dtyp
     return out
 
 
-def logmel_augment_fwd(wave, tables, *, noise, snr_db, freq_start=None, time_start=None, freq_width=48, time_width=None,
+def logmel_augment_fwd(wave, tables, *, noise, snr_db, freq_start=None, time_start=None, freq_width=10, time_width=48,
                        n_frames=3000, out_dtype=torch.float32, channels_last=True):
     """Training-time mel-spectrogram pipeline: mel power -> SpecAugment bands -> noise at a target SNR per mel
     row -> clip layer norm.  wave [B,n] fp32; noise [B,n_frames] or [n_frames] fp32; snr_db [B] fp32;
-    freq_start / time_start int32 [B,2] (negative = no band).  ``time_width`` defaults to the reference's
-    (1 + n // 160) // 8."""
+    freq_start / time_start int32 [B,2] (negative = no band): starts of the bands of ``freq_width`` mel bins and
+    of ``time_width`` frames.  The defaults are what the reference's SpecAugment does to its [80, frames] tensor
+    (datamodule/transforms.py:127,152-177): 80 // 8 = 10 mel bins and 48 frames."""
     lib = _lib.load()
     _need_cuda(wave, noise, snr_db, freq_start, time_start, *tables)
     if wave.dim() != 2 or wave.dtype != torch.float32 or wave.stride(1) != 1:
@@ -328,8 +329,6 @@ def logmel_augment_fwd(wave, tables, *, noise, snr_db, freq_start=None, time_sta
     for st_ in (freq_start, time_start):
         if st_ is not None and (st_.dtype != torch.int32 or tuple(st_.shape) != (B, 2) or not st_.is_contiguous()):
             raise ValueError("band starts must be contiguous int32 [B,2]")
-    if time_width is None:
-        time_width = (1 + n // 160) // 8
     shape = (B, n_frames, 80) if channels_last else (B, 80, n_frames)
     out = torch.empty(shape, dtype=out_dtype, device=wave.device)
     st, sm = (80, 1) if channels_last else (1, n_frames)
@@ -549,6 +548,19 @@ def add3(a, b, c=None):
     lib = _lib.load()
     out = torch.empty_like(a)
     check(lib.avsr_add3(_stream(), _dt(a), a.data_ptr(), b.data_ptr(), _p(c), out.data_ptr(), a.numel()), "avsr_add3")
+    return out
+
+
+def add_table(x, table):
+    """x [..., T, d] + table [T, d] (fp32, contiguous) broadcast over the leading dimensions."""
+    lib = _lib.load()
+    _need_cuda(x, table)
+    if table.dtype != torch.float32 or not table.is_contiguous() or tuple(x.shape[-table.dim():]) != tuple(table.shape):
+        raise ValueError("table must be a contiguous fp32 tensor matching x's trailing dimensions")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(lib.avsr_add_table(_stream(), _dt(x), x.data_ptr(), table.data_ptr(), out.data_ptr(), x.numel(), table.numel()),
+          "avsr_add_table")
     return out
 
 

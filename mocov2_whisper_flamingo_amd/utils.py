@@ -7,6 +7,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import functional as Fn
 from . import ops
 
 
@@ -31,16 +32,41 @@ class PositionalEncoding(nn.Module):
         return self.pe[0, :seq_len]
 
     def forward(self, x):
-        """Stand-alone use: x + pe[:, :T] for a [B,T,d] tensor on the GPU."""
-        B, T, d = x.shape
-        pe = self.pe[0, :T].to(x.dtype).expand(B, T, d).contiguous()
-        return ops.add3(x.contiguous(), pe)
+        """Stand-alone use: x + pe[:, :T] for a [B,T,d] tensor on the GPU (models/utils.py:21-28)."""
+        if x.dim() != 3 or x.shape[1] > self.pe.shape[1] or x.shape[2] != self.pe.shape[2]:
+            raise ValueError(f"expected [B, T <= {self.pe.shape[1]}, {self.pe.shape[2]}], got {tuple(x.shape)}")
+        return _AddTableFn.apply(x, self.pe[0, :x.shape[1]])
+
+
+class _AddTableFn(torch.autograd.Function):
+    """x[b] + table for every batch item; the table is read in place (no expanded copy)."""
+
+    @staticmethod
+    def forward(ctx, x, table):
+        return ops.add_table(x, table.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
 
 
 class Decoder(nn.Module):
-    """Frame-level vocabulary head: one Linear(d_model, vocab_size)."""
+    """Frame-level vocabulary head: one Linear(d_model, vocab_size) (models/utils.py:30-44)."""
 
-    def __init__(self, d_model, vocab_size, enable_logging=False):
+    def __init__(self, d_model, vocab_size, enable_logging=False, dtype=torch.bfloat16):
         super().__init__()
         self.enable_logging = enable_logging
         self.linear = nn.Linear(d_model, vocab_size)
+        self._cache = Fn.WeightCache(dtype)         # AVNet replaces it with the cache it shares with the fusion
+
+    def forward(self, x):
+        """x [B, T, d_model] (or [rows, d_model]) on the GPU -> fp32 logits [B, T, vocab] (models/utils.py:36-44).
+        The logits live in a buffer whose row stride is padded; the returned tensor is a view of it."""
+        lin = self.linear
+        cdt = self._cache.dtype
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if x2.dtype == cdt else x2.to(cdt)
+        wc, wct = self._cache.get(lin.weight)
+        logits = Fn.LinearFn.apply(x2, lin.weight, lin.bias, wc, wct, torch.float32, wct.shape[1],
+                                   (lin.weight, lin.bias, None, 1))
+        return logits.view(*x.shape[:-1], -1)

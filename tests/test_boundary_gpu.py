@@ -1,0 +1,143 @@
+"""The drop-in boundary on the GPU: every sub-module surface the reference exposes, called on its own with the
+reference's signature (models/utils.py:8-44, models/gate_cross_attention.py:8-73,
+models/moco_visual_frontend.py:29-52), and AVNet called the way the reference's trainer calls it - inside an
+fp16 autocast region (train.py:316, precision="16-mixed")."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from mocov2_whisper_flamingo_amd import (AVNet, Decoder, GatedCrossAttentionBlock, LayerNorm, MoCoVisualFrontend,
+                                         PositionalEncoding, WhisperConfig)
+from tests.helpers import max_err, seed_module, synthetic_batch, to_device
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
+MICRO = WhisperConfig(d_model=128, encoder_layers=2, encoder_attention_heads=2, decoder_layers=1,
+                      decoder_attention_heads=2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decoder_forward_standalone(dev, dtype):
+    """Decoder(d, V)(x): Linear d -> V on [B,T,d] (models/utils.py:36-44), forward and backward."""
+    d, V, B, T = 128, 503, 2, 7
+    dec = Decoder(d, V, dtype=dtype)
+    sd = seed_module(dec, 31)
+    dec.to(dev)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, T, d, generator=g)
+    xr = x.clone().requires_grad_(True)
+    w, b = sd["linear.weight"].clone().requires_grad_(True), sd["linear.bias"].clone().requires_grad_(True)
+    ref = F.linear(xr, w, b)
+    dout = torch.randn(B, T, V, generator=g)
+    ref.backward(dout)
+    xd = x.to(dev, dtype).requires_grad_(True)
+    got = dec(xd)
+    assert got.shape == (B, T, V) and got.dtype == torch.float32
+    assert max_err(got, ref) < TOL[dtype]
+    got.backward(dout.to(dev))
+    assert max_err(xd.grad, xr.grad) < TOL[dtype] * 2
+    assert max_err(dec.linear.weight.grad, w.grad) < TOL[dtype] * 3
+    assert max_err(dec.linear.bias.grad, b.grad) < TOL[dtype] * 3
+    # 2-D input, as a caller that has already flattened (B, T) would pass it
+    assert max_err(dec(x.view(B * T, d).to(dev, dtype)), ref.view(B * T, V)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_positional_encoding_and_layernorm_standalone(dev, dtype):
+    """PositionalEncoding.forward = x + pe[:, :T] (models/utils.py:21-28); LayerNorm = fp32 nn.LayerNorm cast
+    back to the input dtype (models/gate_cross_attention.py:8-10)."""
+    d, B, T = 128, 3, 11
+    pe = PositionalEncoding(d).to(dev)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, T, d, generator=g)
+    xd = x.to(dev, dtype).requires_grad_(True)
+    y = pe(xd)
+    want = x.to(dtype).float() + pe.pe[:, :T].cpu()
+    assert y.dtype == dtype and max_err(y, want) < (1e-6 if dtype == torch.float32 else 1e-2)
+    y.sum().backward()
+    assert torch.equal(xd.grad.float().cpu(), torch.ones(B, T, d))
+    with pytest.raises(ValueError):
+        pe(torch.zeros(1, 5001, d, device=dev, dtype=dtype))
+    ln = LayerNorm(d)
+    sd = seed_module(ln, 3)
+    ln.to(dev)
+    got = ln(x.to(dev, dtype))
+    ref = F.layer_norm(x.to(dtype).float(), (d,), sd["weight"], sd["bias"], 1e-5)
+    assert got.dtype == dtype and got.shape == (B, T, d) and max_err(got, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gated_block_standalone_with_and_without_xa(dev, dtype):
+    """GatedCrossAttentionBlock.forward(x, xa=None, mask=None) on its own (models/gate_cross_attention.py:28-50):
+    xa=None skips the attention half; the squeeze quirks for a [B,1,Tk,d] xa / [B,1,Tk] mask (:35-38)."""
+    d, H, B, T, Tk = 128, 2, 2, 9, 13
+    blk = GatedCrossAttentionBlock(d, H, dropout=0.1)
+    sd = seed_module(blk, 41)
+    blk.to(dev).eval()
+    g = torch.Generator().manual_seed(4)
+    x, xa = torch.randn(B, T, d, generator=g), torch.randn(B, Tk, d, generator=g)
+    mask = torch.zeros(B, Tk, dtype=torch.bool)
+    mask[1, 6:] = True
+    ref_ff = oracle.gated_block(sd, "", x, None, None, H)
+    got_ff = blk(x.to(dev, dtype))
+    assert max_err(got_ff, ref_ff) < TOL[dtype]
+    ref = oracle.gated_block(sd, "", x, xa, mask, H)
+    got = blk(x.to(dev, dtype), xa.to(dev, dtype), mask.to(dev))
+    assert max_err(got, ref) < TOL[dtype]
+    got4 = blk(x.to(dev, dtype), xa.to(dev, dtype).unsqueeze(1), mask.to(dev).unsqueeze(1))
+    assert torch.equal(got4, got)
+
+
+def test_visual_frontend_accepts_six_dimensional_input(dev):
+    """MoCoVisualFrontend.forward(x, x_len) with x [B,1,T,3,H,W] (models/moco_visual_frontend.py:32-34)."""
+    m = MoCoVisualFrontend()
+    sd = seed_module(m, 11)
+    m.compute_dtype = torch.float32
+    m.to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    video = torch.randn(2, 4, 3, 32, 32, generator=g)
+    lens = torch.tensor([4, 2])
+    ref = oracle.visual_frontend(sd, "", video, lens, False, {})
+    got = m(video.unsqueeze(1).to(dev), lens.to(dev))
+    assert got.shape == (2, 4, 2048) and max_err(got, ref) < 1e-3
+    assert (got[1, 2:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_avnet_inside_fp16_autocast(dev, dtype):
+    """train.py:316 runs the module under Lightning's precision="16-mixed", i.e. inside
+    torch.autocast("cuda", torch.float16) with a GradScaler.  The module computes in its own dtype (bf16 or fp32
+    copies of the weights it manages itself): the autocast region must not change its results - the logits stay
+    fp32 and bit-identical to the call outside the region - and a scaled loss built on them with torch ops
+    back-propagates through the HIP kernels to gradients that, once unscaled, match the oracle."""
+    m = AVNet("audiovisual", None, 96, (128, 2, 4, 3000, 512, 0.1), 503, whisper_config=MICRO, dtype=dtype)
+    sd = seed_module(m, 21)
+    m.to(dev).eval()
+    batch = synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=5)
+    bd = to_device(batch, dev)
+
+    def inputs():
+        return (bd["audio"], bd["audio_mask"], bd["video"], bd["video_mask"], bd["video_lengths"].clone())
+
+    plain = m(inputs()).detach().clone()
+    scale = 1024.0                                               # a GradScaler's loss scale
+    with torch.autocast("cuda", dtype=torch.float16):
+        logits = m(inputs())
+        assert logits.dtype == torch.float32
+        lp = F.log_softmax(logits, -1).transpose(0, 1)          # autocast runs these in fp32 (train.py:100-101)
+        ctc = F.ctc_loss(lp, bd["target_ids"], bd["audio_lengths"], bd["target_lengths"].reshape(-1), blank=0,
+                         reduction="mean", zero_infinity=True)
+        ce = F.cross_entropy(logits[:, :4].reshape(-1, 503), bd["target_ids"].reshape(-1), label_smoothing=0.1)
+        loss = ctc + ce
+    assert torch.equal(logits.detach(), plain)
+    (loss * scale).backward()
+    loss_r, _, _, logits_r, grads_r, _ = oracle.training_step(sd, batch, 2, 2, masked_row="zero")
+    assert max_err(logits, logits_r) < TOL[dtype]
+    assert abs(loss.item() - loss_r.item()) < TOL[dtype] * max(1.0, abs(loss_r.item()))
+    params = dict(m.named_parameters())
+    for k, gr in grads_r.items():
+        got = params[k].grad.float().cpu() / scale
+        assert torch.isfinite(got).all(), k
+        assert (got - gr).abs().max().item() < TOL[dtype] * 5 * max(1.0, gr.abs().max().item()), k
