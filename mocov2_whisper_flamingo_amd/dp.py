@@ -17,10 +17,15 @@ Lightning's ``DDPStrategy(find_unused_parameters=True)`` + ``gradient_clip_val``
 * clipping needs no extra collective: after the all-reduce every rank holds the
   same averaged gradient and computes the same norm locally.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import ops
+
+# Debug switch: hand gloo the device tensors themselves when ranks share a GPU (see FlatTrainer._reduce_bucket).
+GLOO_DEVICE_TENSORS = os.environ.get("AVSR_GLOO_DEVICE_TENSORS", "0") == "1"
 
 
 def trainable_parameters(model):
@@ -38,7 +43,8 @@ class FlatTrainer:
     """
 
     def __init__(self, model, *, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_grad_norm=1.0,
-                 bucket_mb=64, process_group=None, overlap=True, force_collective=False, grad_stream=True, fused_step=False):
+                 bucket_mb=64, process_group=None, overlap=True, force_collective=False, grad_stream=True, fused_step=False,
+                 accumulate=1):
         self.model = model
         self.named = trainable_parameters(model)
         if not self.named:
@@ -58,6 +64,14 @@ class FlatTrainer:
         self.fused_step = bool(fused_step)
         self._pre_scale = 1.0
         self._clean = False
+        # accumulate = k (accumulate_grad_batches, config.py:42 / train.py:322): k backward passes - use
+        # ``backward(loss)``, which divides the loss by k as Lightning does - feed one optimizer step; the buckets are
+        # all-reduced during (overlap) or after the k-th pass only
+        self.accumulate = int(accumulate)
+        if self.accumulate < 1:
+            raise ValueError("accumulate must be >= 1")
+        self._passes = 0              # backward passes since the last zero_grad
+        self._in_backward = False
 
         # backward reaches parameters roughly in reverse registration order: lay the flat buffer out in
         # that order so buckets fill front to back as backward proceeds
@@ -113,14 +127,25 @@ class FlatTrainer:
     def _arm(self):
         for b in self.buckets:
             b["left"] = len(b["params"])
+            b["launched"] = False
         self._seen = set()
+        self._passes = 0
+        self._in_backward = False
+
+    def _gloo_on_gpu(self):
+        return self.on_gpu and dist.get_backend(self.group) == "gloo"
 
     def _reduce_bucket(self, b):
         lo, hi = b["range"]
         view = self.flat_grad[lo:hi]
-        if self.on_gpu and dist.get_backend(self.group) == "gloo":
-            # gloo (rehearsals of the multi-rank path on one GPU): exchange a host copy, synchronously - its
-            # CUDA-tensor path stalled after a few large all-reduces on this stack
+        b["launched"] = True
+        if self._gloo_on_gpu() and not GLOO_DEVICE_TENSORS:
+            # gloo with ranks that share one GPU (rehearsals of the multi-rank path): exchange a host copy,
+            # synchronously.  c10d's gloo backend stages device tensors through streams it takes from the
+            # HIGH-PRIORITY pool; with two processes on one GPU a high-priority queue that waits on the same
+            # process's backlogged normal-priority queues stalled for good here - the same stall a high-priority
+            # tail stream produced in this configuration.  RCCL's stream has normal priority and every rank has
+            # its own GPU, so the path below is not affected.
             if self.grad_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.grad_stream)
             host = view.cpu()
@@ -137,8 +162,25 @@ class FlatTrainer:
             w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._works.append(w)
 
+    def _backward_done(self):
+        self._in_backward = False
+
     def _on_grad_ready(self, p):
-        # a parameter can be announced twice in one step (by the kernels' own notification and by autograd's
+        if not self._in_backward:
+            # first gradient of a backward pass: count the pass and have the engine tell us when it ends
+            self._in_backward = True
+            self._passes += 1
+            torch.autograd.Variable._execution_engine.queue_callback(self._backward_done)
+            if self._passes > self.accumulate:
+                # the buckets of this step are already being all-reduced in place: more gradient added now would
+                # race with the collective and never be reduced
+                raise RuntimeError(
+                    f"backward pass {self._passes} since zero_grad(), but FlatTrainer(accumulate={self.accumulate}) "
+                    "all-reduces during pass number `accumulate`; construct it with accumulate=k to add up k "
+                    "micro-batches per optimizer step")
+        if self._passes < self.accumulate:
+            return                                    # not the last micro-batch: accumulate locally, no exchange
+        # a parameter can be announced twice in one pass (by the kernels' own notification and by autograd's
         # post-accumulate hook, which also runs for a gradient that was handed back as None): count it once
         if id(p) in self._seen:
             return
@@ -147,6 +189,21 @@ class FlatTrainer:
         b["left"] -= 1
         if b["left"] == 0:
             self._reduce_bucket(b)
+
+    def backward(self, loss):
+        """Back-propagate one micro-batch: ``loss / accumulate`` (Lightning divides the loss by
+        accumulate_grad_batches, so the summed gradient is the mean over the micro-batches).  Returns True when
+        this was the last micro-batch of the optimizer step (time for reduce_gradients() and step())."""
+        done = self._passes if self.overlap else self._manual_passes()
+        (loss / self.accumulate if self.accumulate > 1 else loss).backward()
+        if not self.overlap:
+            self._passes = done + 1
+        return self._passes >= self.accumulate
+
+    def _manual_passes(self):
+        if self._passes >= self.accumulate:
+            raise RuntimeError(f"more than accumulate={self.accumulate} backward passes since zero_grad()")
+        return self._passes
 
     def zero_grad(self):
         self.join_gradients()
@@ -170,7 +227,7 @@ class FlatTrainer:
             # no hooks: every gradient is in place and the current stream has joined the gradient stream, so the
             # buckets are reduced right here, in stream order (the collective library's own stream does the
             # work; nothing of this object's runs beside it)
-            staged = self.on_gpu and dist.get_backend(self.group) == "gloo"
+            staged = self._gloo_on_gpu() and not GLOO_DEVICE_TENSORS      # see _reduce_bucket
             for b in self.buckets:
                 lo, hi = b["range"]
                 view = self.flat_grad[lo:hi]
@@ -183,7 +240,7 @@ class FlatTrainer:
             self._to_mean()
             return
         for b in self.buckets:
-            if b["left"] > 0:                         # unused parameter in the bucket
+            if not b["launched"]:                     # unused parameter in the bucket, or fewer passes than `accumulate`
                 self._reduce_bucket(b)
         for w in self._works:
             w.wait()

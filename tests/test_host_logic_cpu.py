@@ -141,6 +141,74 @@ def test_dp_gradient_mean_over_gloo_equals_full_batch(fused):
     assert nb > 1 and worst < 1e-4
 
 
+def _accum_worker(rank, world, port, q, overlap):
+    """Gradient accumulation over k = 3 micro-batches on 2 ranks: a loss that is linear in every trainable
+    parameter gives known gradients (its coefficients), through autograd's own accumulation and hooks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        m, _ = micro_model()
+        k = 3
+        tr = FlatTrainer(m, bucket_mb=0.25, overlap=overlap, accumulate=k)
+        named = trainable_parameters(m)
+
+        def coeffs(r, micro):
+            g = torch.Generator().manual_seed(1000 * r + micro)
+            return [torch.randn(p.shape, generator=g) for _, p in named]
+
+        launched_before_last = None
+        for cycle in range(2):                                   # two optimizer steps: the pass counter re-arms
+            tr.zero_grad()
+            for micro in range(k):
+                c = coeffs(rank, 10 * cycle + micro)
+                loss = sum((p * ci).sum() for (_, p), ci in zip(named, c))
+                last = tr.backward(loss)
+                assert last == (micro == k - 1)
+                if micro == k - 2:
+                    launched_before_last = any(b["launched"] for b in tr.buckets)
+            tr.reduce_gradients()
+            want = [sum(coeffs(r, 10 * cycle + micro)[i] for r in range(world) for micro in range(k)) / (world * k)
+                    for i in range(len(named))]
+            worst = max(((p.grad - w).abs().max() / w.abs().max()).item() for (_, p), w in zip(named, want))
+            assert worst < 1e-5, worst
+            assert not launched_before_last                      # nothing was exchanged before the k-th pass
+        err = None
+        if overlap:          # one pass too many after the buckets went out: refused, not silently wrong
+            try:
+                tr.backward(sum((p * 1.0).sum() for _, p in named))
+            except RuntimeError as e:
+                err = str(e)
+            assert err is not None and "accumulate" in err
+        if rank == 0:
+            q.put(("ok", worst, len(tr.buckets)))
+        dist.barrier()
+    except Exception as e:
+        if rank == 0:
+            q.put(("error", repr(e), 0))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_dp_gradient_accumulation_over_gloo(overlap):
+    """accumulate_grad_batches (config.py:42, train.py:322): k backward passes per optimizer step, the loss of
+    each divided by k, ONE gradient exchange - launched from the hooks of the k-th pass (overlap) or after it."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, q, overlap)) for r in range(world)]
+    for p in procs:
+        p.start()
+    status, worst, nb = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+    assert status == "ok", worst
+    assert all(p.exitcode == 0 for p in procs)
+    assert nb > 1
+
+
 def test_adaptive_time_mask_draws_like_the_reference():
     """Host-side draw of AdaptiveTimeMask (datamodule/transforms.py:27-45): one candidate per started 25 frames,
     mask lengths below the window, nothing outside the clip; a zero first draw skips the mask after its start
