@@ -47,7 +47,8 @@ const char* avsr_version(void);
  * models/moco_visual_frontend.py:20).
  *
  * epilogue, in this order:  v = acc * alpha;  v *= scale[n];  v += bias[n];
- *   v = act(v);  v = residual[m,n] + g * v  (g = tanh(*gate) or 1);
+ *   v = act(v);  (optional extended steps, see the end of the struct;)
+ *   v = residual[m,n] + g * v  (g = tanh(*gate) or 1);
  *   (AVSR_ACT_RELU_AFTER_RESIDUAL applies the ReLU after the residual add;)
  *   optional per-column partial sums of the PRE-activation value into the
  *   col_sum / col_sumsq slabs for batch-norm statistics.
@@ -80,6 +81,15 @@ typedef struct {
         int32_t enabled;
         int32_t H, W, C, KH, KW, stride, pad_h, pad_w, OH, OW;
     } conv;
+    /* extended epilogue (dense products, batch 1, act NONE or GELU; all optional, zero = off), applied in this
+     * order after scale / bias:  pre[m,n] = v (a second output of out_dtype: the value BEFORE the activation and
+     * the gate);  v = act(v);  v *= gelu'(mul_gelu_grad_of[m,n]) (backward through a GELU whose input was saved);
+     * v = dropout(v) with keep decision generator(seed, m*N + n), kept values scaled by 1/(1-p_drop);
+     * then the residual / gate step above. */
+    void* pre; int64_t ldp;
+    const void* mul_gelu_grad_of; int64_t ld_aux;
+    float p_drop;
+    uint64_t seed;
 } avsr_gemm_t;
 
 int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g);
@@ -104,6 +114,13 @@ int avsr_layernorm_fwd(avsr_stream_t stream, int in_dtype, int out_dtype, const 
 int avsr_layernorm_bwd(avsr_stream_t stream, int x_dtype, int g_dtype, const void* dy, int64_t lddy,
                        const void* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                        void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int64_t D);
+
+/* the same with the gradient that reaches x past the norm added in: dx = LN'(dy) + dres (dres of g_dtype,
+ * may be NULL) - the residual connection around a pre-norm branch, models/gate_cross_attention.py:43,47 */
+int avsr_layernorm_bwd_res(avsr_stream_t stream, int x_dtype, int g_dtype, const void* dy, int64_t lddy,
+                           const void* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
+                           void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int64_t D,
+                           const void* dres, int64_t lddr);
 
 /* ------------------------------------------------------------------------
  * Attention, head_dim 64.  Element (b,t,h,d) of Q/K/V/O lives at
@@ -138,6 +155,49 @@ int avsr_attn_bwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, 
                   void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv,
                   const uint8_t* key_mask, const float* lse, float* d_ws, int64_t B, int64_t H, int64_t Tq,
                   int64_t Tk, int64_t head_dim, float scale, float p_drop, uint64_t seed);
+
+/* ------------------------------------------------------------------------
+ * One tanh-gated cross-attention block, forward and backward, as one call each:
+ * GatedCrossAttentionBlock.forward (models/gate_cross_attention.py:28-50) with its nn.MultiheadAttention
+ * (:16,40), the two fp32 LayerNorms (:8-10,17-18), the GELU feed-forward (:23-26) and the tanh gates (:19-20):
+ *   x1  = x  + tanh(gate_attn) * MHA(LN1(x), xa, xa, key_padding_mask)        (skipped when xa == NULL)
+ *   out = x1 + tanh(gate_ff)   * Dropout(W2 gelu(W1 LN2(x1) + b1) + b2)
+ * x, out: [B*Tq, d]; xa: [B*Tk, d]; all row-major and dense, of `dtype` (AVSR_F32 or AVSR_BF16), d = 64*H.
+ * Weights are the caller's copies in `dtype`: W as nn.Linear stores it ([out, in]) for the forward, W^T
+ * ([in, ld >= out]) for the input gradients of the backward (NULL is fine for a forward-only call); biases,
+ * LayerNorm parameters and the two gates are the fp32 parameters themselves (gates: device scalars).
+ * The call queues the block's kernel chain on `stream`: LayerNorm, projection GEMMs, the flash attention of
+ * avsr_attn_fwd (key mask, attention dropout with seed_attn), and GEMMs whose epilogues apply bias, GELU,
+ * feed-forward dropout (element (row, col) keeps iff generator(seed_ff, row*d + col) says so), tanh gate and
+ * residual.  `saved` (avsr_gated_xattn_fwd_workspace_bytes) receives the activations the backward needs.
+ * Backward: dx = d(loss)/dx; d(loss)/d(xa) is written to dxa, or added to it when accumulate_dxa != 0 (xa
+ * feeds every block of the fusion); parameter gradients are ACCUMULATED into the fp32 buffers of
+ * avsr_xattn_grads_t (shapes of the parameters; the gate gradients are single floats).
+ * `workspace`: avsr_gated_xattn_bwd_workspace_bytes bytes of scratch.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int32_t dtype;
+    int64_t B, Tq, Tk, d, H, d_ff;
+    float p_drop;                    /* 0 in eval mode */
+    uint64_t seed_attn, seed_ff;
+    const void* w_in;  const void* w_inT;  int64_t ld_inT;  const float* b_in;    /* attn.in_proj_weight [3d, d], ^T [d, ld] */
+    const void* w_out; const void* w_outT; int64_t ld_outT; const float* b_out;   /* attn.out_proj       [d, d]            */
+    const void* w_fc1; const void* w_fc1T; int64_t ld_fc1T; const float* b_fc1;   /* ff.0                [d_ff, d]         */
+    const void* w_fc2; const void* w_fc2T; int64_t ld_fc2T; const float* b_fc2;   /* ff.2                [d, d_ff]         */
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;                                   /* attn_ln, ff_ln                        */
+    const float *gate_attn, *gate_ff;
+} avsr_xattn_block_t;
+typedef struct {
+    float *dw_in, *db_in, *dw_out, *db_out, *dw_fc1, *db_fc1, *dw_fc2, *db_fc2;
+    float *dln1_g, *dln1_b, *dln2_g, *dln2_b, *dgate_attn, *dgate_ff;
+} avsr_xattn_grads_t;
+int64_t avsr_gated_xattn_fwd_workspace_bytes(const avsr_xattn_block_t* blk);
+int64_t avsr_gated_xattn_bwd_workspace_bytes(const avsr_xattn_block_t* blk);
+int avsr_gated_xattn_fwd(avsr_stream_t stream, const avsr_xattn_block_t* blk, const void* x, const void* xa,
+                         const uint8_t* key_mask, void* out, void* saved);
+int avsr_gated_xattn_bwd(avsr_stream_t stream, const avsr_xattn_block_t* blk, const void* x, const void* xa,
+                         const uint8_t* key_mask, const void* saved, const void* dout, void* dx, void* dxa,
+                         int accumulate_dxa, const avsr_xattn_grads_t* grads, void* workspace);
 
 /* ------------------------------------------------------------------------
  * Mel front end: waveform [batch, n_samples] fp32 -> 80-bin mel features.

@@ -29,7 +29,26 @@ class GemmDesc(_c.Structure):
         ("alpha", _f32), ("scale", _vp), ("bias", _vp), ("act", _i32),
         ("residual", _vp), ("ldr", _i64), ("res_period", _i64), ("gate", _vp),
         ("col_sum", _vp), ("col_sumsq", _vp), ("conv", ConvDesc),
+        ("pre", _vp), ("ldp", _i64), ("mul_gelu_grad_of", _vp), ("ld_aux", _i64), ("p_drop", _f32), ("seed", _u64),
     ]
+
+
+class XattnBlock(_c.Structure):
+    _fields_ = [
+        ("dtype", _i32), ("B", _i64), ("Tq", _i64), ("Tk", _i64), ("d", _i64), ("H", _i64), ("d_ff", _i64),
+        ("p_drop", _f32), ("seed_attn", _u64), ("seed_ff", _u64),
+        ("w_in", _vp), ("w_inT", _vp), ("ld_inT", _i64), ("b_in", _vp),
+        ("w_out", _vp), ("w_outT", _vp), ("ld_outT", _i64), ("b_out", _vp),
+        ("w_fc1", _vp), ("w_fc1T", _vp), ("ld_fc1T", _i64), ("b_fc1", _vp),
+        ("w_fc2", _vp), ("w_fc2T", _vp), ("ld_fc2T", _i64), ("b_fc2", _vp),
+        ("ln1_g", _vp), ("ln1_b", _vp), ("ln2_g", _vp), ("ln2_b", _vp),
+        ("gate_attn", _vp), ("gate_ff", _vp),
+    ]
+
+
+class XattnGrads(_c.Structure):
+    _fields_ = [(n, _vp) for n in ("dw_in", "db_in", "dw_out", "db_out", "dw_fc1", "db_fc1", "dw_fc2", "db_fc2",
+                                   "dln1_g", "dln1_b", "dln2_g", "dln2_b", "dgate_attn", "dgate_ff")]
 
 
 # name -> (restype, argtypes); must list every symbol include/avsr_hip.h declares
@@ -38,10 +57,17 @@ SIGNATURES = {
     "avsr_gemm_nt": (_i32, [_vp, _c.POINTER(GemmDesc)]),
     "avsr_layernorm_fwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _f32]),
     "avsr_layernorm_bwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64]),
+    "avsr_layernorm_bwd_res": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
+                                      _vp, _i64]),
     "avsr_attn_fwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
                              _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64, _i32]),
     "avsr_attn_bwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
                              _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64]),
+    "avsr_gated_xattn_fwd_workspace_bytes": (_i64, [_c.POINTER(XattnBlock)]),
+    "avsr_gated_xattn_bwd_workspace_bytes": (_i64, [_c.POINTER(XattnBlock)]),
+    "avsr_gated_xattn_fwd": (_i32, [_vp, _c.POINTER(XattnBlock), _vp, _vp, _vp, _vp, _vp]),
+    "avsr_gated_xattn_bwd": (_i32, [_vp, _c.POINTER(XattnBlock), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
+                                    _c.POINTER(XattnGrads), _vp]),
     "avsr_logmel_dft_table_floats": (_i64, []),
     "avsr_logmel_mel_table_floats": (_i64, []),
     "avsr_logmel_tables": (_i32, [_vp, _i32, _vp, _vp]),

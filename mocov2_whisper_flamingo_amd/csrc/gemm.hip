@@ -17,6 +17,8 @@ struct GemmP {
     const void* res; long ldr; int res_period; const float* gate; float* csum; float* csq;
     int H, W, Cc, KH, KW, stride, pad_h, pad_w, OH, OW;
     int tiles_m, tiles_n, vec_ok;
+    // extended epilogue (dense products only): second output, dropout, multiply by gelu'(aux)
+    void* pre; long ldp; const void* aux; long ldaux; float p_drop; unsigned long long seed; int ext;
 };
 
 // Block id -> (tile_m, tile_n).  Blocks are dealt round-robin over the 8 XCDs;
@@ -88,6 +90,17 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, f32x4 acc, int m, 
     }
     const bool post_relu = p.act == AVSR_ACT_RELU_AFTER_RESIDUAL;
     if (m >= p.M) return;
+    if (p.ext) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nb + r;
+            if (n >= p.N) continue;
+            if (p.pre) ((OutT*)p.pre)[cbase + (long)m * p.ldp + n] = from_f32<OutT>(pre[r]);
+            if (p.aux) v[r] *= gelu_erf_grad(to_f32<OutT>(((const OutT*)p.aux)[(long)m * p.ldaux + n]));
+            if (p.p_drop > 0.f)
+                v[r] = avsr_keep(p.seed, (uint64_t)((long)m * p.N + n), p.p_drop) ? v[r] * (1.0f / (1.0f - p.p_drop)) : 0.f;
+        }
+    }
     OutT* cp = (OutT*)p.C + cbase + (long)m * p.ldc + nb;
     const OutT* rp = p.res ? (const OutT*)p.res + (long)(p.res_period > 0 ? m % p.res_period : m) * p.ldr + nb : nullptr;
     if (p.vec_ok && nb + 3 < p.N) {
@@ -146,7 +159,7 @@ __device__ __forceinline__ void stats_quad(const GemmP& p, f32x4 s, f32x4 s2, in
 // costs several scalar branches per element) and the row loop is NOT unrolled: the epilogue runs once per
 // tile, so its instructions are fetched cold, and straight-line code four times as long measured 17-30 %
 // slower on the K = 768 encoder GEMMs (instruction-cache misses, not arithmetic).
-template <int BN_, typename OutT, int ACT, bool CONV, int MI>
+template <int BN_, typename OutT, int ACT, bool CONV, int MI, bool EXT = false>
 __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][BN_ / 32], char* lds, const float* sb,
                                               int m0, int n0, int tm, long cbase, int lane, int wave) {
     constexpr int NJ = BN_ / 32, LDT = BN_ + 4, CG = BN_ / 8, RS = 256 / CG;
@@ -193,8 +206,18 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
             for (int e = 0; e < 8; ++e) {
                 float x = fmaf(v[e], sc[e], bi[e]);
                 if (stats) { s1[e] += x; s2[e] = fmaf(x, x, s2[e]); }
+                if constexpr (EXT) {            // second output: the value before the activation / gate
+                    if (p.pre && n + e < p.N) ((OutT*)p.pre)[cbase + (long)m * p.ldp + n + e] = from_f32<OutT>(x);
+                }
                 if (ACT == AVSR_ACT_GELU) x = gelu_erf_fast(x);
                 else if (ACT == AVSR_ACT_RELU) x = fmaxf(x, 0.f);
+                if constexpr (EXT) {
+                    if (n + e < p.N) {
+                        if (p.aux) x *= gelu_erf_grad(to_f32<OutT>(((const OutT*)p.aux)[(long)m * p.ldaux + n + e]));
+                        if (p.p_drop > 0.f)
+                            x = avsr_keep(p.seed, (uint64_t)((long)m * p.N + n + e), p.p_drop) ? x * (1.0f / (1.0f - p.p_drop)) : 0.f;
+                    }
+                }
                 v[e] = x;
             }
             OutT* cp = (OutT*)p.C + cbase + (long)m * p.ldc + n;
@@ -263,9 +286,16 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
     }
 }
 
-template <int BN_, typename OutT, bool CONV, int MI>
+template <int BN_, typename OutT, bool CONV, int MI, bool EXT = false>
 __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][BN_ / 32], char* lds, const float* sb,
                                               int m0, int n0, int tm, long cbase, int lane, int wave) {
+    if constexpr (EXT) {                        // instantiations of their own: the plain kernels' code is untouched
+        if (p.act == AVSR_ACT_GELU)
+            epilogue_body<BN_, OutT, AVSR_ACT_GELU, CONV, MI, true>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+        else
+            epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV, MI, true>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+        return;
+    }
     switch (p.act) {                            // block-uniform
         case AVSR_ACT_GELU: epilogue_body<BN_, OutT, AVSR_ACT_GELU, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
         case AVSR_ACT_RELU: epilogue_body<BN_, OutT, AVSR_ACT_RELU, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
@@ -366,7 +396,7 @@ template <int BN_, int G_NST, int BM_ = G_BM> constexpr int gemm_lds_bytes() {
 // 2 = convolution whose channel count is a multiple of the K-step: a K-step lies inside ONE filter tap, so the tap is
 // a scalar, a lane keeps one byte offset per piece (its pixel) and a bit per tap (inside the image or padding), and
 // the K loop carries no per-lane index arithmetic beyond one 64-bit add and the zero-page select.
-template <int BN_, int G_NST, int CONV, typename OutT, int BM_ = G_BM>
+template <int BN_, int G_NST, int CONV, typename OutT, int BM_ = G_BM, bool EXT = false>
 // Single-stage instantiations: dense operands at three workgroups per CU (168 registers, no spills) - four (128
 // registers) is faster for some products run alone, but with two or three streams sharing the chip the step is
 // 2.5 % faster at three; the convolution form stays at four (no difference in the step, faster alone).
@@ -590,7 +620,7 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : 
         wait_vmcnt<0>();                        // drain the re-loaded steps before the LDS is reused
     }
     STAMP(3);
-    epilogue_tile<BN_, OutT, CONV != 0, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+    epilogue_tile<BN_, OutT, CONV != 0, MI, EXT>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
 #ifdef GEMM_STAMPS
     STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -740,13 +770,22 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     p.res = g->residual; p.ldr = g->ldr; p.res_period = (int)g->res_period; p.gate = g->gate; p.csum = g->col_sum; p.csq = g->col_sumsq;
     p.H = g->conv.H; p.W = g->conv.W; p.Cc = g->conv.C; p.KH = g->conv.KH; p.KW = g->conv.KW;
     p.stride = g->conv.stride; p.pad_h = g->conv.pad_h; p.pad_w = g->conv.pad_w; p.OH = g->conv.OH; p.OW = g->conv.OW;
+    p.pre = g->pre; p.ldp = g->ldp; p.aux = g->mul_gelu_grad_of; p.ldaux = g->ld_aux;
+    p.p_drop = g->p_drop; p.seed = g->seed;
+    p.ext = (g->pre || g->mul_gelu_grad_of || g->p_drop > 0.f) ? 1 : 0;
+    if (p.ext) {
+        // the extended epilogue exists for dense, unbatched products with no activation or GELU
+        if (conv || g->batch != 1 || (g->act != AVSR_ACT_NONE && g->act != AVSR_ACT_GELU)) return AVSR_EUNSUPPORTED;
+        if (g->p_drop < 0.f || g->p_drop >= 1.f) return AVSR_EINVAL;
+        if ((g->pre && g->ldp < g->N) || (g->mul_gelu_grad_of && g->ld_aux < g->N)) return AVSR_EINVAL;
+    }
     const size_t osz = g->out_dtype == AVSR_BF16 ? 2 : 4;
     // vector path: every row start of C (and of the residual) 16-byte aligned
     p.vec_ok = ((g->ldc * osz) % 16 == 0) && aligned_to(g->C, 16) && ((g->strideC * osz) % 16 == 0) &&
                (!g->residual || (((g->ldr * osz) % 16 == 0) && aligned_to(g->residual, 16)));
     // batched launches: a residual only as a table shared by every batch entry (row m % res_period), no statistics
     if (g->batch > 1 && (g->col_sum || (g->residual && g->res_period <= 0))) return AVSR_EUNSUPPORTED;
-    int bn = (bf && g->N <= 64) ? 64 : 128;
+    int bn = (bf && g->N <= 64 && !p.ext) ? 64 : 128;
     // A grid of a few dozen 128 x 128 tiles leaves most CUs idle while each busy one grinds through its tile's whole
     // K loop at one CU's MFMA rate: 64 x 64 tiles put four times as many CUs to work on a quarter of the tile each.
     const bool small = bf && !conv && !g->col_sum && g->batch == 1 && bn == 128 &&
@@ -756,7 +795,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     // quarter of the chip idle while 52 CUs run a third tile; 750 tiles of 96 rows are 2.93 per CU).
     int bm = G_BM;
     if (small) bm = 64;
-    if (bf && !conv && !g->col_sum && bn == 128 && g->batch == 1) {
+    if (bf && !conv && !g->col_sum && bn == 128 && g->batch == 1 && !p.ext) {
         const long tn = (p.N + 127) / 128;
         const long t128 = ((p.M + 127) / 128) * tn, t96 = ((p.M + 95) / 96) * tn;
         auto fill = [](long t, long rows, long M, long tnn) {      // useful rows / rows the busiest CU's rounds pay for
@@ -774,7 +813,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     }
     // 256-row tiles (a wave owns 128 x 64: a quarter less LDS traffic per MFMA) pay off only where the tile
     // count stays far above the CU count: +8 % on 4096^3 and larger, a loss on every product of this network.
-    if (bf && !conv && !g->col_sum && bn == 128 && g->batch == 1 && bm == G_BM &&
+    if (bf && !conv && !g->col_sum && bn == 128 && g->batch == 1 && bm == G_BM && !p.ext &&
         ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 2 * G_NST_SWITCH_TILES && p.K >= 2048) bm = 256;
     const int tmS = bf ? bm : FM, tnS = bf ? bn : FN;
     p.tiles_m = (p.M + tmS - 1) / tmS;
@@ -809,6 +848,18 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         }                                                                                                      \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
     } while (0)
+#define LAUNCHX(BNV, NSTV, OT, BMV)                                                                            \
+    do {                                                                                                       \
+        static bool attr_set = false;                                                                          \
+        constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV, BMV>();                                            \
+        auto kfn = gemm_bf16_kernel<BNV, NSTV, 0, OT, BMV, true>;                                              \
+        if (!attr_set) {                                                                                       \
+            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)   \
+                != hipSuccess) return AVSR_EHIP;                                                               \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
+    } while (0)
 #define LAUNCH_CV_OT(BNV, NSTV)                                                                                \
     do {                                                                                                       \
         if (conv) { if (of) LAUNCHB(BNV, NSTV, 1, float); else LAUNCHB(BNV, NSTV, 1, bf16_t); }                \
@@ -820,7 +871,14 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     // single-stage ones its extra per-lane state spills inside the K loop (measured: half the rate).
     const bool conv_fast = bf && conv && g->conv.C % G_BK == 0 && g->conv.KH * g->conv.KW <= 32 &&
                            (g->M / ((int64_t)g->conv.OH * g->conv.OW)) * g->conv.H * g->conv.W * g->conv.C * 2 < (1ll << 31);
-    if (bf) {
+    if (bf && p.ext) {
+        // extended epilogue: a second set of instantiations, restricted to the tile shapes the trainable tail uses
+        const bool single = ntiles >= G_NST_SWITCH_TILES;
+        if (small) { if (of) LAUNCHX(64, 4, float, 64); else LAUNCHX(64, 4, bf16_t, 64); }
+        else if (ntiles <= G_DEEP_TILES) { if (of) LAUNCHX(128, 4, float, 128); else LAUNCHX(128, 4, bf16_t, 128); }
+        else if (single) { if (of) LAUNCHX(128, 1, float, 128); else LAUNCHX(128, 1, bf16_t, 128); }
+        else { if (of) LAUNCHX(128, 2, float, 128); else LAUNCHX(128, 2, bf16_t, 128); }
+    } else if (bf) {
         const bool single = ntiles * g->batch >= G_NST_SWITCH_TILES;
         if (small) {
             if (of) LAUNCHBM(64, 4, float, 64); else LAUNCHBM(64, 4, bf16_t, 64);
@@ -841,6 +899,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
 #undef LAUNCH
 #undef LAUNCHB
 #undef LAUNCHBM
+#undef LAUNCHX
 #undef LAUNCH_CV_OT
 #undef LAUNCH_FAST_OT
     return avsr_launch_status();

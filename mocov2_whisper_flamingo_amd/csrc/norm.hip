@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TG* __restrict
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, TG* __restrict__ dx, long lddx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rows, int D) {
+                                                            int rows, int D, const TG* __restrict__ dres, long lddr) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nw = gridDim.x * 4;
@@ -137,6 +137,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TG* __restrict
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2);
+                if (dres) {                     // the gradient that reaches x past the norm (a residual connection)
+                    float rv[4];
+                    load4<TG>(dres + (long)row * lddr + c * 4, rv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += rv[e];
+                }
                 store4<TG>(dx + (long)row * lddx + c * 4, o);
             }
         }
@@ -194,14 +200,23 @@ extern "C" int avsr_layernorm_fwd(avsr_stream_t stream, int in_dtype, int out_dt
 extern "C" int avsr_layernorm_bwd(avsr_stream_t stream, int x_dtype, int g_dtype, const void* dy, int64_t lddy,
                                   const void* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                                   void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int64_t D) {
+    return avsr_layernorm_bwd_res(stream, x_dtype, g_dtype, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dgamma, dbeta,
+                                  rows, D, nullptr, 0);
+}
+
+extern "C" int avsr_layernorm_bwd_res(avsr_stream_t stream, int x_dtype, int g_dtype, const void* dy, int64_t lddy,
+                                      const void* x, int64_t ldx, const float* gamma, const float* mean,
+                                      const float* rstd, void* dx, int64_t lddx, float* dgamma, float* dbeta,
+                                      int64_t rows, int64_t D, const void* dres, int64_t lddr) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return AVSR_EINVAL;
-    if (D % 4 || D > 64 * 4 * LN_MAXV || ldx % 4 || lddy % 4 || lddx % 4) return AVSR_EUNSUPPORTED;
+    if (D % 4 || D > 64 * 4 * LN_MAXV || ldx % 4 || lddy % 4 || lddx % 4 || (dres && lddr % 4)) return AVSR_EUNSUPPORTED;
     long nb = (rows + 7) / 8;        // ~2 rows per wave; one atomic per column per block at the end
     if (nb > 256) nb = 256;
     dim3 grid((unsigned)nb), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define L(TX, TG) hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TG>), grid, block, 0, s, (const TG*)dy, (long)lddy, (const TX*)x, \
-                                     (long)ldx, gamma, mean, rstd, (TG*)dx, (long)lddx, dgamma, dbeta, (int)rows, (int)D)
+                                     (long)ldx, gamma, mean, rstd, (TG*)dx, (long)lddx, dgamma, dbeta, (int)rows, (int)D, \
+                                     (const TG*)dres, (long)lddr)
     if (x_dtype == AVSR_F32 && g_dtype == AVSR_F32) L(float, float);
     else if (x_dtype == AVSR_F32 && g_dtype == AVSR_BF16) L(float, bf16_t);
     else if (x_dtype == AVSR_BF16 && g_dtype == AVSR_BF16) L(bf16_t, bf16_t);

@@ -266,6 +266,59 @@ class AttnFn(Function):
         return dq, dk, dv, None, None, None, None, None
 
 
+class SharedGrad:
+    """Gradient buffer of a tensor that feeds several nodes (the fusion's ``xa`` feeds every block): the nodes'
+    backward kernels add into ONE buffer and the last of them to run hands it to autograd, instead of autograd
+    summing one tensor per consumer with add kernels of its own."""
+
+    def __init__(self, consumers):
+        self.consumers = self.left = consumers
+        self.buf = None
+
+    def arrived(self, buf):
+        """One consumer has added its share into ``buf``; returns the sum once all have, else None."""
+        self.buf = buf
+        self.left -= 1
+        if self.left > 0:
+            return None
+        self.left, self.buf = self.consumers, None        # ready for another backward over a retained graph
+        return buf
+
+
+class GatedXattnBlockFn(Function):
+    """One GatedCrossAttentionBlock (models/gate_cross_attention.py:28-50) as a single autograd node over the
+    avsr_gated_xattn_fwd / _bwd entry points.  ``params`` are the block's 14 parameters in the order
+    in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, ff.0.weight, ff.0.bias, ff.2.weight, ff.2.bias,
+    attn_ln.weight, attn_ln.bias, ff_ln.weight, ff_ln.bias, attn_gate, ff_gate - they only route gradients;
+    the kernels read the descriptor's compute-dtype copies."""
+
+    @staticmethod
+    def forward(ctx, x, xa, key_mask, blk, shared, *params):
+        out, saved = ops.gated_xattn_fwd(blk, x, xa, key_mask)
+        ctx.save_for_backward(x, xa, key_mask, saved)
+        ctx.blk, ctx.shared, ctx.params = blk, shared, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, xa, key_mask, saved = ctx.saved_tensors
+        params = ctx.params
+        sinks = [grad_sink(p) for p in params]
+        direct = all(s is not None for s in sinks)
+        grads = sinks if direct else [torch.zeros(p.shape, dtype=torch.float32, device=x.device) for p in params]
+        shared = ctx.shared if xa is not None else None
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        dx, dxa = ops.gated_xattn_bwd(ctx.blk, x, xa, key_mask, saved, dout, grads,
+                                      dxa=shared.buf if shared is not None else None)
+        if shared is not None:                      # hand the summed gradient over once, from the last consumer
+            dxa = shared.arrived(dxa)
+        if direct:
+            for p in params:
+                grad_done(p)
+            return (dx, dxa, None, None, None) + (None,) * len(params)
+        return (dx, dxa, None, None, None) + tuple(grads)
+
+
 class Add3Fn(Function):
     @staticmethod
     def forward(ctx, a, b, c):

@@ -38,8 +38,40 @@ class GatedCrossAttentionBlock(nn.Module):
         self.d_model, self.n_heads, self.p_drop = d_model, n_heads, dropout
         self._cache = None          # WeightCache, set by the owner
         self._seed_fn = lambda tag: 0
+        # fused: the block is ONE autograd node over avsr_gated_xattn_fwd / _bwd (element-wise steps in the GEMM
+        # epilogues, one host call per direction); False = the kernel-by-kernel composition, kept for comparison
+        self.fused = True
 
-    def forward(self, x, xa=None, mask=None):
+    def _params(self):
+        a, f = self.attn, self.ff
+        return (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, f[0].weight, f[0].bias,
+                f[2].weight, f[2].bias, self.attn_ln.weight, self.attn_ln.bias, self.ff_ln.weight, self.ff_ln.bias,
+                self.attn_gate, self.ff_gate)
+
+    def _forward_fused(self, x, xa, mask, shared=None):
+        B, T, d = x.shape
+        cache = self._cache
+        p = self.p_drop if self.training else 0.0
+        Tk = xa.shape[1] if xa is not None else 1
+        prm = self._params()
+        weights = [cache.get(w) for w in (prm[0], prm[2], prm[4], prm[6])]
+        vectors = (prm[1], prm[3], prm[5], prm[7]) + prm[8:]
+        blk = Fn.ops.xattn_block_desc(x.dtype, B, T, Tk, d, self.n_heads, self.ff[0].weight.shape[0], p,
+                                      self._seed_fn("attn") if p > 0 else 0, self._seed_fn("ff") if p > 0 else 0,
+                                      weights, [v.detach() for v in vectors])
+        km = None if (mask is None or xa is None) else mask.to(torch.uint8).contiguous()
+        x2 = x.reshape(B * T, d)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        xa2 = None
+        if xa is not None:
+            xa2 = xa.reshape(B * Tk, d)
+            xa2 = xa2 if xa2.is_contiguous() else xa2.contiguous()
+            if shared is None:
+                shared = Fn.SharedGrad(1)
+        out = Fn.GatedXattnBlockFn.apply(x2, xa2, km, blk, shared, *prm)
+        return out.view(B, T, d)
+
+    def forward(self, x, xa=None, mask=None, _shared=None):
         """x [B,T,d]; xa [B,Tk,d] or None (skips attention); mask bool/uint8 [B,Tk], True = padded key."""
         if xa is not None and xa.dim() == 4 and xa.size(1) == 1:
             xa = xa.squeeze(1)
@@ -53,6 +85,8 @@ class GatedCrossAttentionBlock(nn.Module):
         cache = self._cache
         if cache is None or cache.dtype != x.dtype:        # stand-alone block: its own weight copies in x's dtype
             cache = self._cache = Fn.WeightCache(x.dtype)
+        if self.fused:
+            return self._forward_fused(x, xa, mask, _shared)
         x2 = x.reshape(B * T, d)
         if xa is not None:
             Tk = xa.shape[1]
@@ -106,6 +140,10 @@ class GatedCrossModalFusion(nn.Module):
                       self._cache.get(self.audio_proj.weight)).view(B, T, d)
         xa = Fn.linear(v.reshape(B * Tk, d), self.video_proj.weight, self.video_proj.bias,
                        self._cache.get(self.video_proj.weight)).view(B, Tk, d)
+        # xa feeds every block: their backward kernels add into one gradient buffer (see functional.SharedGrad)
+        shared = None
+        if torch.is_grad_enabled() and xa.requires_grad and all(layer.fused for layer in self.layers):
+            shared = Fn.SharedGrad(len(self.layers))
         for layer in self.layers:
-            x = layer(x, xa, video_mask)
+            x = layer(x, xa, video_mask, _shared=shared)
         return self.ln_post(x)

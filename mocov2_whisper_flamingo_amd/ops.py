@@ -551,6 +551,80 @@ def add3(a, b, c=None):
     return out
 
 
+def xattn_block_desc(dtype, B, Tq, Tk, d, H, d_ff, p_drop, seed_attn, seed_ff, weights, vectors):
+    """Descriptor of one gated cross-attention block for gated_xattn_fwd / _bwd.  ``weights`` = four (W, W^T)
+    pairs in ``dtype`` for in_proj, out_proj, ff.0, ff.2 (W as nn.Linear stores it, W^T [in, ld >= out]);
+    ``vectors`` = fp32 tensors (b_in, b_out, b_fc1, b_fc2, ln1_g, ln1_b, ln2_g, ln2_b, gate_attn, gate_ff).
+    The descriptor keeps the tensors alive."""
+    blk = _lib.XattnBlock()
+    blk.dtype, blk.B, blk.Tq, blk.Tk, blk.d, blk.H, blk.d_ff = _DT[dtype], B, Tq, Tk, d, H, d_ff
+    blk.p_drop, blk.seed_attn, blk.seed_ff = float(p_drop), int(seed_attn), int(seed_ff)
+    _need_cuda(*vectors)
+    for name, (w, wt) in zip(("in", "out", "fc1", "fc2"), weights):
+        _need_cuda(w, wt)
+        if w.dtype != dtype or wt.dtype != dtype or not w.is_contiguous() or wt.stride(-1) != 1:
+            raise ValueError(f"weight copies of {name} must be contiguous tensors of the compute dtype")
+        setattr(blk, "w_" + name, w.data_ptr())
+        setattr(blk, f"w_{name}T", wt.data_ptr())
+        setattr(blk, f"ld_{name}T", wt.stride(0))
+    for name, v in zip(("b_in", "b_out", "b_fc1", "b_fc2", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "gate_attn", "gate_ff"),
+                       vectors):
+        if v.dtype != torch.float32 or not v.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous fp32 tensor")
+        setattr(blk, name, v.data_ptr())
+    blk._keep = (weights, vectors)
+    return blk
+
+
+def gated_xattn_fwd(blk, x, xa, key_mask):
+    """One gated cross-attention block forward.  x [B*Tq, d], xa [B*Tk, d] or None, key_mask uint8 [B, Tk] or
+    None -> (out [B*Tq, d], saved activations for gated_xattn_bwd)."""
+    lib = _lib.load()
+    _need_cuda(x, xa, key_mask)
+    if not x.is_contiguous() or (xa is not None and not xa.is_contiguous()):
+        raise ValueError("gated_xattn operands must be dense [rows, d] tensors")
+    if _dt(x) != blk.dtype or tuple(x.shape) != (blk.B * blk.Tq, blk.d):
+        raise ValueError("x does not match the block descriptor")
+    if xa is not None and (_dt(xa) != blk.dtype or tuple(xa.shape) != (blk.B * blk.Tk, blk.d)):
+        raise ValueError("xa does not match the block descriptor")
+    if key_mask is not None and (key_mask.dtype != torch.uint8 or tuple(key_mask.shape) != (blk.B, blk.Tk)
+                                 or not key_mask.is_contiguous()):
+        raise ValueError("key_mask must be a contiguous uint8 [B, Tk] tensor")
+    out = torch.empty_like(x)
+    saved = torch.empty(int(lib.avsr_gated_xattn_fwd_workspace_bytes(ctypes.byref(blk))), dtype=torch.uint8, device=x.device)
+    check(lib.avsr_gated_xattn_fwd(_stream(), ctypes.byref(blk), x.data_ptr(), _p(xa), _p(key_mask), out.data_ptr(),
+                                   saved.data_ptr()), "avsr_gated_xattn_fwd")
+    return out, saved
+
+
+XATTN_GRAD_NAMES = ("dw_in", "db_in", "dw_out", "db_out", "dw_fc1", "db_fc1", "dw_fc2", "db_fc2",
+                    "dln1_g", "dln1_b", "dln2_g", "dln2_b", "dgate_attn", "dgate_ff")
+
+
+def gated_xattn_bwd(blk, x, xa, key_mask, saved, dout, grads, dxa=None):
+    """Backward of gated_xattn_fwd.  ``grads``: 14 fp32 tensors (order XATTN_GRAD_NAMES) the parameter gradients
+    are accumulated into.  ``dxa``: buffer to ADD d(loss)/d(xa) to, or None for a fresh tensor.
+    Returns (dx, dxa)."""
+    lib = _lib.load()
+    _need_cuda(dout, dxa, *grads)
+    if not dout.is_contiguous() or _dt(dout) != blk.dtype or dout.shape != x.shape:
+        raise ValueError("dout must be a dense tensor shaped like x, in the compute dtype")
+    g = _lib.XattnGrads()
+    for name, t in zip(XATTN_GRAD_NAMES, grads):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous fp32 tensor")
+        setattr(g, name, t.data_ptr())
+    dx = torch.empty_like(x)
+    accumulate = dxa is not None
+    if xa is not None and dxa is None:
+        dxa = torch.empty_like(xa)
+    ws = torch.empty(int(lib.avsr_gated_xattn_bwd_workspace_bytes(ctypes.byref(blk))), dtype=torch.uint8, device=x.device)
+    check(lib.avsr_gated_xattn_bwd(_stream(), ctypes.byref(blk), x.data_ptr(), _p(xa), _p(key_mask), saved.data_ptr(),
+                                   dout.data_ptr(), dx.data_ptr(), _p(dxa) if xa is not None else None, int(accumulate),
+                                   ctypes.byref(g), ws.data_ptr()), "avsr_gated_xattn_bwd")
+    return dx, (dxa if xa is not None else None)
+
+
 def add_table(x, table):
     """x [..., T, d] + table [T, d] (fp32, contiguous) broadcast over the leading dimensions."""
     lib = _lib.load()

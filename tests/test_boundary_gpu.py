@@ -141,3 +141,54 @@ def test_avnet_inside_fp16_autocast(dev, dtype):
         got = params[k].grad.float().cpu() / scale
         assert torch.isfinite(got).all(), k
         assert (got - gr).abs().max().item() < TOL[dtype] * 5 * max(1.0, gr.abs().max().item()), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("training", [False, True])
+def test_fused_block_entry_matches_kernel_by_kernel_path_and_oracle(dev, dtype, training):
+    """avsr_gated_xattn_fwd / _bwd (one call per direction, element-wise steps in the GEMM epilogues) against
+    the kernel-by-kernel composition of the same block and, in eval mode, against the oracle - forward, input
+    gradients and all 14 parameter gradients.  Shapes with B*T and B*Tk that are not multiples of 8 (the
+    zero-padded transposes of the dW products), Tq != Tk, a ragged key mask with one fully masked clip, and in
+    training mode both dropouts drawn from the same seeds on both paths."""
+    import copy
+    d, H, B, T, Tk = 128, 2, 3, 25, 17
+    blk = GatedCrossAttentionBlock(d, H, dropout=0.2)
+    sd = seed_module(blk, 43)
+    blk.to(dev).train(training)
+    blk._seed_fn = lambda tag: {"attn": 1234567, "ff": 7654321}[tag]
+    ref_blk = copy.deepcopy(blk)
+    ref_blk._seed_fn = blk._seed_fn
+    ref_blk.fused, blk.fused = False, True
+    g = torch.Generator().manual_seed(6)
+    x, xa = torch.randn(B, T, d, generator=g), torch.randn(B, Tk, d, generator=g)
+    dout = torch.randn(B, T, d, generator=g)
+    mask = torch.zeros(B, Tk, dtype=torch.bool)
+    mask[1, 9:] = True
+    mask[2, :] = True                                    # every key masked: the attention output is the out-proj bias
+    outs = []
+    for m in (blk, ref_blk):
+        xd, xad = x.to(dev, dtype).requires_grad_(True), xa.to(dev, dtype).requires_grad_(True)
+        y = m(xd, xad, mask.to(dev))
+        y.backward(dout.to(dev, dtype))
+        outs.append((y.detach(), xd.grad, xad.grad, {k: p.grad for k, p in m.named_parameters()}))
+    (y, dx, dxa, gp), (yr, dxr, dxar, gpr) = outs
+    tol = TOL[dtype]
+    assert max_err(y, yr) < tol and max_err(dx, dxr) < 2 * tol and max_err(dxa, dxar) < 2 * tol
+    for k in gpr:
+        assert gp[k] is not None, k
+        rel = 0.15 if (k.endswith("_gate") and dtype == torch.bfloat16) else 3 * tol
+        assert max_err(gp[k], gpr[k]) < rel, k
+    if not training:
+        leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xr, xar = x.clone().requires_grad_(True), xa.clone().requires_grad_(True)
+        ref = oracle.gated_block(leaf, "", xr, xar, mask, H, masked_row="zero")
+        ref.backward(dout)
+        assert max_err(y, ref) < tol and max_err(dx, xr.grad) < 2 * tol and max_err(dxa, xar.grad) < 2 * tol
+        for k in gpr:
+            rel = 0.15 if (k.endswith("_gate") and dtype == torch.bfloat16) else 3 * tol
+            assert max_err(gp[k], leaf[k].grad) < rel, k
+    # without xa the attention half is skipped on the fused path too
+    y0 = blk(x.to(dev, dtype))
+    y0r = ref_blk(x.to(dev, dtype))
+    assert max_err(y0, y0r) < tol

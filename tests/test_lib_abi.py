@@ -30,21 +30,25 @@ def test_header_is_plain_c():
 
 
 def test_struct_layout_matches_header():
-    from mocov2_whisper_flamingo_amd._lib import GemmDesc
-    src = r'''
-#include <stdio.h>
-#include <stddef.h>
-#include "avsr_hip.h"
-int main(void){ printf("%zu %zu %zu %zu %zu\n", sizeof(avsr_gemm_t), offsetof(avsr_gemm_t, A), offsetof(avsr_gemm_t, alpha),
-                       offsetof(avsr_gemm_t, gate), offsetof(avsr_gemm_t, conv)); return 0; }
-'''
+    """Every field of the three descriptor structs sits where the header puts it (offsets from gcc)."""
+    from mocov2_whisper_flamingo_amd._lib import GemmDesc, XattnBlock, XattnGrads
     import subprocess, tempfile
+    pairs = ((GemmDesc, "avsr_gemm_t"), (XattnBlock, "avsr_xattn_block_t"), (XattnGrads, "avsr_xattn_grads_t"))
+    lines = []
+    for cls, cname in pairs:
+        lines.append(f'printf("%zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("%zu\\n", offsetof({cname}, {fname}));')
+    src = "#include <stdio.h>\n#include <stddef.h>\n#include \"avsr_hip.h\"\nint main(void){\n" + "\n".join(lines) + "\nreturn 0; }\n"
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
-        out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, text=True).stdout.split()
-    got = [ctypes.sizeof(GemmDesc), GemmDesc.A.offset, GemmDesc.alpha.offset, GemmDesc.gate.offset, GemmDesc.conv.offset]
-    assert [int(x) for x in out] == got
+        out = [int(x) for x in subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, text=True).stdout.split()]
+    got = []
+    for cls, _ in pairs:
+        got.append(ctypes.sizeof(cls))
+        got.extend(getattr(cls, fname).offset for fname, _ in cls._fields_)
+    assert out == got
 
 
 def test_product_path_has_no_cpu_fallback():
