@@ -122,6 +122,20 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// the same through the erfc polynomial of gelu_erf_fast (|error| <= 1.5e-7 on the cdf): for GEMM epilogues
+__device__ __forceinline__ float gelu_erf_grad_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(t, poly, 1.421413741f);
+    poly = fmaf(t, poly, -0.284496736f);
+    poly = fmaf(t, poly, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);      // exp(-x^2 / 2)
+    const float q = 0.5f * poly * t * e;                                       // erfc(z) / 2
+    const float cdf = x < 0.f ? q : 1.0f - q;
+    return fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }

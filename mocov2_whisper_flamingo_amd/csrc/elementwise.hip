@@ -53,23 +53,26 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ x
     }
 }
 
-// out[n] (+)= sum_m x[m][n]; one 1024-thread block per 64 columns, 16 waves split the rows.
+// out[n] (+)= sum_m x[m][n]; a 1024-thread block per 64 columns and row slice, 16 waves split the slice's rows.
+// One slice (gridDim.y == 1): plain store, fixed summation order.  Several slices (tall operands): each block adds
+// its partial with one atomic per column; `out` then has to hold the value to add to (zero for a plain sum).
 template <typename T>
 __global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ x, long ld, int M, int N, float* __restrict__ out,
-                                                      int accumulate) {
+                                                      int accumulate, int rows_per_slice) {
     __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
+    const int m_begin = blockIdx.y * rows_per_slice, m_end = min(M, m_begin + rows_per_slice);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (n < N) {
-        int m = w;
-        for (; m + 48 < M; m += 64) {
+        int m = m_begin + w;
+        for (; m + 48 < m_end; m += 64) {
             s0 += to_f32<T>(x[(long)m * ld + n]);
             s1 += to_f32<T>(x[(long)(m + 16) * ld + n]);
             s2 += to_f32<T>(x[(long)(m + 32) * ld + n]);
             s3 += to_f32<T>(x[(long)(m + 48) * ld + n]);
         }
-        for (; m < M; m += 16) s0 += to_f32<T>(x[(long)m * ld + n]);
+        for (; m < m_end; m += 16) s0 += to_f32<T>(x[(long)m * ld + n]);
     }
     part[w][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -77,7 +80,8 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ x, l
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += part[i][lane];
-        out[n] = accumulate ? out[n] + t : t;
+        if (gridDim.y > 1) atomicAdd(out + n, t);
+        else out[n] = accumulate ? out[n] + t : t;
     }
 }
 
@@ -109,8 +113,9 @@ __global__ __launch_bounds__(256) void gated_residual_fwd_kernel(const T* __rest
         out[i] = from_f32<T>(to_f32<T>(x[i]) + g * v);
     }
 }
-// dy = tanh(g) * drop(dout);  dgate += (1 - tanh(g)^2) * sum(dout * drop(y))
-template <typename T>
+// dy = tanh(g) * drop(dout);  dgate += (1 - tanh(g)^2) * sum(dout * drop(y)).  VEC: 8 consecutive elements per thread
+// and step (16-byte accesses for bf16); every workgroup ends in ONE atomic on the gate gradient.
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void gated_residual_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                                  const float* __restrict__ gate, T* __restrict__ dy,
                                                                  float* __restrict__ dgate, long n, float pdrop, uint64_t seed) {
@@ -119,11 +124,27 @@ __global__ __launch_bounds__(256) void gated_residual_bwd_kernel(const T* __rest
     const float ks = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
     const long stride = (long)gridDim.x * blockDim.x;
     float acc = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float d = to_f32<T>(dout[i]);
-        if (pdrop > 0.f) d = avsr_keep(seed, (uint64_t)i, pdrop) ? d * ks : 0.f;
-        acc += d * to_f32<T>(y[i]);
-        dy[i] = from_f32<T>(g * d);
+    if constexpr (VEC) {
+        typedef __attribute__((ext_vector_type(8))) T vec8;
+        for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride * 8) {
+            const vec8 dv = *(const vec8*)(dout + i), yv = *(const vec8*)(y + i);
+            vec8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float d = to_f32<T>(dv[e]);
+                if (pdrop > 0.f) d = avsr_keep(seed, (uint64_t)(i + e), pdrop) ? d * ks : 0.f;
+                acc += d * to_f32<T>(yv[e]);
+                o[e] = from_f32<T>(g * d);
+            }
+            *(vec8*)(dy + i) = o;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            float d = to_f32<T>(dout[i]);
+            if (pdrop > 0.f) d = avsr_keep(seed, (uint64_t)i, pdrop) ? d * ks : 0.f;
+            acc += d * to_f32<T>(y[i]);
+            dy[i] = from_f32<T>(g * d);
+        }
     }
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) atomicAdd(dgate, (1.f - g * g) * acc);
@@ -312,10 +333,21 @@ extern "C" int avsr_colsum(avsr_stream_t stream, int dtype, const void* x, int64
                            int accumulate) {
     if (!x || !out || M <= 0 || N <= 0) return AVSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)((N + 63) / 64)), block(1024);
-    if (dtype == AVSR_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)x, (long)ld, (int)M, (int)N, out, accumulate);
-    else if (dtype == AVSR_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, (long)ld, (int)M, (int)N, out, accumulate);
-    else return AVSR_EINVAL;
+    if (dtype != AVSR_F32 && dtype != AVSR_BF16) return AVSR_EINVAL;
+    // tall operands: slices of 1024 rows, as many as fill the chip about twice with the column groups
+    const long col_groups = (N + 63) / 64;
+    long slices = 1;
+    if (M > 2048) {
+        slices = (M + 1023) / 1024;
+        const long want = (512 + col_groups - 1) / col_groups;
+        if (slices > want) slices = want;
+        if (slices < 1) slices = 1;
+    }
+    const int rows_per_slice = (int)((M + slices - 1) / slices);
+    if (slices > 1 && !accumulate && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s) != hipSuccess) return AVSR_EHIP;
+    dim3 grid((unsigned)col_groups, (unsigned)slices), block(1024);
+    if (dtype == AVSR_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)x, (long)ld, (int)M, (int)N, out, accumulate, rows_per_slice);
+    else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, (long)ld, (int)M, (int)N, out, accumulate, rows_per_slice);
     return avsr_launch_status();
 }
 
@@ -354,10 +386,18 @@ extern "C" int avsr_gated_residual_bwd(avsr_stream_t stream, int dtype, const vo
                                        void* dy, float* dgate, int64_t n, float p_drop, uint64_t seed) {
     if (!dout || !y || !gate || !dy || !dgate || n <= 0 || p_drop < 0.f || p_drop >= 1.f) return AVSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(grid_for(n, 256, 64)), block(256);      // few workgroups: each ends in ONE atomic on the gate gradient
-    if (dtype == AVSR_F32) hipLaunchKernelGGL(gated_residual_bwd_kernel<float>, grid, block, 0, s, (const float*)dout, (const float*)y, gate, (float*)dy, dgate, (long)n, p_drop, seed);
-    else if (dtype == AVSR_BF16) hipLaunchKernelGGL(gated_residual_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dout, (const bf16_t*)y, gate, (bf16_t*)dy, dgate, (long)n, p_drop, seed);
-    else return AVSR_EINVAL;
+    if (dtype != AVSR_F32 && dtype != AVSR_BF16) return AVSR_EINVAL;
+    const size_t es = dtype == AVSR_BF16 ? 2 : 4;
+    const bool vec = n % 8 == 0 && (((uintptr_t)dout | (uintptr_t)y | (uintptr_t)dy) % (8 * es)) == 0;
+    // each workgroup ends in ONE atomic on the gate gradient: 64 workgroups up to 2 M elements (the step is launch
+    // bound there), then one per 32 K elements up to twice the CU count
+    long blocks = (n + 32767) / 32768;
+    blocks = blocks < 64 ? 64 : (blocks > 512 ? 512 : blocks);
+    dim3 grid(grid_for(n, vec ? 2048 : 256, blocks)), block(256);
+#define L(T, V) hipLaunchKernelGGL((gated_residual_bwd_kernel<T, V>), grid, block, 0, s, (const T*)dout, (const T*)y, gate, (T*)dy, dgate, (long)n, p_drop, seed)
+    if (dtype == AVSR_F32) { if (vec) L(float, true); else L(float, false); }
+    else { if (vec) L(bf16_t, true); else L(bf16_t, false); }
+#undef L
     return avsr_launch_status();
 }
 

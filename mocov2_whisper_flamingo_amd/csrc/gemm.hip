@@ -182,6 +182,8 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
         for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     }
     const bool full = p.vec_ok && n + 7 < p.N;
+    // 16-byte accesses to the second output and the saved GELU inputs: the host checked their alignment
+    const bool ext_vec = EXT && p.ext == 2;
     const bool has_res = p.res != nullptr;
     const bool stats = p.csum != nullptr;
 #pragma unroll
@@ -202,23 +204,58 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
             if (m >= p.M) continue;
             const f32x4 c0 = *(const f32x4*)&Ct[lr * LDT + cg * 8], c1 = *(const f32x4*)&Ct[lr * LDT + cg * 8 + 4];
             float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            float pv[8], av[8];                 // EXT: the second output's values / the saved GELU inputs
+            if constexpr (EXT) {
+                if (p.aux) {
+                    const OutT* ap = (const OutT*)p.aux + (long)m * p.ldaux + n;
+                    if (full && ext_vec) {
+                        if constexpr (sizeof(OutT) == 4) {
+                            const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { av[e] = a0[e]; av[4 + e] = a1[e]; }
+                        } else {
+                            const bf16x8 a0 = *(const bf16x8*)ap;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) av[e] = (float)a0[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) av[e] = n + e < p.N ? to_f32<OutT>(ap[e]) : 0.f;
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float x = fmaf(v[e], sc[e], bi[e]);
                 if (stats) { s1[e] += x; s2[e] = fmaf(x, x, s2[e]); }
-                if constexpr (EXT) {            // second output: the value before the activation / gate
-                    if (p.pre && n + e < p.N) ((OutT*)p.pre)[cbase + (long)m * p.ldp + n + e] = from_f32<OutT>(x);
-                }
+                if constexpr (EXT) pv[e] = x;   // second output: the value before the activation / gate
                 if (ACT == AVSR_ACT_GELU) x = gelu_erf_fast(x);
                 else if (ACT == AVSR_ACT_RELU) x = fmaxf(x, 0.f);
                 if constexpr (EXT) {
-                    if (n + e < p.N) {
-                        if (p.aux) x *= gelu_erf_grad(to_f32<OutT>(((const OutT*)p.aux)[(long)m * p.ldaux + n + e]));
-                        if (p.p_drop > 0.f)
-                            x = avsr_keep(p.seed, (uint64_t)((long)m * p.N + n + e), p.p_drop) ? x * (1.0f / (1.0f - p.p_drop)) : 0.f;
-                    }
+                    if (p.aux) x *= gelu_erf_grad_fast(av[e]);
+                    if (p.p_drop > 0.f)
+                        x = avsr_keep(p.seed, (uint64_t)((long)m * p.N + n + e), p.p_drop) ? x * (1.0f / (1.0f - p.p_drop)) : 0.f;
                 }
                 v[e] = x;
+            }
+            if constexpr (EXT) {
+                if (p.pre) {
+                    OutT* pp = (OutT*)p.pre + cbase + (long)m * p.ldp + n;
+                    if (full && ext_vec) {
+                        if constexpr (sizeof(OutT) == 4) {
+                            *(f32x4*)pp = (f32x4){pv[0], pv[1], pv[2], pv[3]};
+                            *(f32x4*)(pp + 4) = (f32x4){pv[4], pv[5], pv[6], pv[7]};
+                        } else {
+                            bf16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)pv[e];
+                            *(bf16x8*)pp = o;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) if (n + e < p.N) pp[e] = from_f32<OutT>(pv[e]);
+                    }
+                }
             }
             OutT* cp = (OutT*)p.C + cbase + (long)m * p.ldc + n;
             const OutT* rp = has_res ? (const OutT*)p.res + (long)(p.res_period > 0 ? m % p.res_period : m) * p.ldr + n : nullptr;
@@ -774,6 +811,9 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     p.p_drop = g->p_drop; p.seed = g->seed;
     p.ext = (g->pre || g->mul_gelu_grad_of || g->p_drop > 0.f) ? 1 : 0;
     if (p.ext) {
+        const size_t osz_ = g->out_dtype == AVSR_BF16 ? 2 : 4;
+        if ((!g->pre || (aligned_to(g->pre, 16) && (g->ldp * osz_) % 16 == 0)) &&
+            (!g->mul_gelu_grad_of || (aligned_to(g->mul_gelu_grad_of, 16) && (g->ld_aux * osz_) % 16 == 0))) p.ext = 2;
         // the extended epilogue exists for dense, unbatched products with no activation or GELU
         if (conv || g->batch != 1 || (g->act != AVSR_ACT_NONE && g->act != AVSR_ACT_GELU)) return AVSR_EUNSUPPORTED;
         if (g->p_drop < 0.f || g->p_drop >= 1.f) return AVSR_EINVAL;

@@ -211,7 +211,8 @@ extern "C" int avsr_layernorm_bwd_res(avsr_stream_t stream, int x_dtype, int g_d
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return AVSR_EINVAL;
     if (D % 4 || D > 64 * 4 * LN_MAXV || ldx % 4 || lddy % 4 || lddx % 4 || (dres && lddr % 4)) return AVSR_EUNSUPPORTED;
     long nb = (rows + 7) / 8;        // ~2 rows per wave; one atomic per column per block at the end
-    if (nb > 256) nb = 256;
+    const long cap = rows > 8192 ? 1024 : 256;      // tall operands: the row stream, not the atomics, sets the time
+    if (nb > cap) nb = cap;
     dim3 grid((unsigned)nb), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define L(TX, TG) hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TG>), grid, block, 0, s, (const TG*)dy, (long)lddy, (const TX*)x, \
