@@ -1,0 +1,150 @@
+"""Parity at the sizes and in the modes the benchmark runs (BASELINE.json configurations 2, 4 and 5), against the
+CPU oracle on identical seeded weights and inputs:
+
+* the Whisper-small encoder at full size on one 30 s clip, and two-layer stacks at Whisper-medium (D = 1024,
+  16 heads) and Whisper-large-v2 (D = 1280, 20 heads) widths - fp32 within 1e-3, bf16 within 2e-2;
+* the whole visual frontend on one clip of 75 frames 96 x 96 (running statistics, and batch statistics);
+* AVNet.training_step in the benchmark's mode - bf16 compute, batch-statistics BatchNorm, both dropouts with the
+  device generator replayed on the host - end to end: loss, logits and every gradient.
+
+A randomly initialised ResNet-50 with batch-statistics BN amplifies any perturbation about 1.3x per block, which
+is a property of random weights, not of the kernels.  These tests seed the trunk the way trained residual
+networks look (the last BN gain of every block small: 0.15 x), so end-to-end tolerances are meaningful."""
+import pytest
+import torch
+
+import oracle
+from mocov2_whisper_flamingo_amd import AVNet, MoCoVisualFrontend, WhisperConfig, WhisperModel
+from tests.helpers import max_err, seed_module, synthetic_batch, to_device
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
+MICRO = WhisperConfig(d_model=128, encoder_layers=2, encoder_attention_heads=2, decoder_layers=1,
+                      decoder_attention_heads=2)
+
+
+def tame_residual_branches(module, sd, prefix=""):
+    """Scale the last BatchNorm gain of every Bottleneck (bn3.weight) by 0.15 in the module and in its fp32 state
+    dict: each block then adds a small correction to its input, as in a trained network."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if name.endswith("bn3.weight"):
+                p.mul_(0.15)
+                sd[prefix + name] = p.detach().cpu().clone().float()
+    return sd
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name,layers", [("small", 12), ("medium", 2), ("large-v2", 2)])
+def test_whisper_encoder_at_benchmark_widths(dev, dtype, name, layers):
+    torch.set_num_threads(16)
+    full = WhisperConfig.from_name(name)
+    cfg = WhisperConfig(d_model=full.d_model, encoder_layers=layers, encoder_attention_heads=full.encoder_attention_heads,
+                        with_decoder=False)
+    m = WhisperModel(cfg)
+    sd = seed_module(m, 7)
+    m.to(dev)
+    mel = torch.randn(1, 80, 3000, generator=torch.Generator().manual_seed(3))
+    ref = oracle.whisper_encoder(sd, "encoder.", mel, cfg.encoder_attention_heads)
+    got = m.encoder(mel.to(dev), dtype=dtype)[0]
+    assert got.shape == ref.shape == (1, 1500, full.d_model)
+    assert max_err(got, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype,training", [(torch.float32, False), (torch.bfloat16, False), (torch.float32, True),
+                                            (torch.bfloat16, True)])
+def test_visual_frontend_full_clip(dev, dtype, training):
+    """One clip of 75 frames 96 x 96 through the 3D stem and all 16 Bottlenecks: 25 x 25 -> 13 x 13 -> 7 x 7 ->
+    4 x 4 feature maps, ragged length (frames past it come out zero)."""
+    torch.set_num_threads(16)
+    m = MoCoVisualFrontend()
+    sd = tame_residual_branches(m, seed_module(m, 11))
+    m.compute_dtype = dtype
+    m.to(dev).train(training)
+    video = torch.randn(1, 75, 3, 96, 96, generator=torch.Generator().manual_seed(5))
+    lens = torch.tensor([61])
+    video[0, 61:] = 0
+    new_stats = {}
+    ref = oracle.visual_frontend(sd, "", video, lens, training, new_stats)
+    got = m(video.to(dev), lens.to(dev))
+    assert got.shape == ref.shape == (1, 75, 2048)
+    assert (got[0, 61:] == 0).all()
+    assert max_err(got, ref) < TOL[dtype] * (2 if training else 1)
+    if training:
+        now = m.state_dict()
+        for k in ("frontend3D.1.running_var", "MoCoModel.layer3.5.bn2.running_mean", "MoCoModel.layer4.2.bn3.running_var"):
+            assert max_err(now[k], new_stats[k]) < (5e-3 if dtype == torch.float32 else 2e-2), k
+
+
+def test_training_step_in_the_benchmark_mode(dev):
+    """bf16 compute + batch-statistics BN + attention / feed-forward dropout, end to end against the oracle with
+    the keep masks replayed from the device generator: loss, logits, every gradient of the trainable tail."""
+    from tests.philox_ref import attn_keep_mask, keep_mask
+    dtype, p = torch.bfloat16, 0.1
+    m = AVNet("audiovisual", None, 96, (128, 2, 4, 3000, 512, p), 503, whisper_config=MICRO, dtype=dtype)
+    sd = seed_module(m, 21)
+    sd = tame_residual_branches(m.visual_model, sd, "visual_model.")
+    m.to(dev).train()
+    batch = synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=17)
+    loss, ctc, ce, logits = m.training_step(to_device(batch, dev))
+    B, T, H, d = 2, 6, 2, 128
+    drop = {"attn": [], "ff": []}
+    for i in range(2):
+        drop["attn"].append(torch.from_numpy(attn_keep_mask(m._dropout_seed(f"fusion.{i}.attn"), (B, H, T, T), p)))
+        drop["ff"].append(torch.from_numpy(keep_mask(m._dropout_seed(f"fusion.{i}.ff"), (B * T, d), p)).view(B, T, d))
+    loss_r, ctc_r, ce_r, logits_r, grads_r, _ = oracle.training_step(sd, batch, 2, 2, training=True, drop=drop, p_drop=p,
+                                                                     masked_row="zero")
+    tol = TOL[dtype]
+    assert max_err(logits, logits_r) < tol
+    assert abs(loss.item() - loss_r.item()) < tol * max(1.0, abs(loss_r.item()))
+    assert abs(ctc.item() - ctc_r.item()) < tol * max(1.0, abs(ctc_r.item()))
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k, gr in grads_r.items():
+        scale = max(1.0, gr.abs().max().item())
+        assert (params[k].grad.float().cpu() - gr).abs().max().item() < 5 * tol * scale, k
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_config2_model_end_to_end(dev, training):
+    """BASELINE.json configuration 2 at its real sizes except the batch (2 clips instead of 8): Whisper-small
+    (D 768, 12 layers, 12 heads), 75 frames 96 x 96, fusion width 512 x 8 heads x 3 blocks, vocabulary 51865,
+    bf16 compute; eval mode, and the benchmark's train mode (batch-statistics BN + dropout, masks replayed).
+    Loss, logits, greedy ids where the reference's top-2 margin exceeds the tolerance, and the gradients of the
+    head and of the first fusion block against the oracle."""
+    from tests.helpers import MODELARGS
+    from tests.philox_ref import attn_keep_mask, keep_mask
+    torch.set_num_threads(16)
+    dtype, p, V = torch.bfloat16, 0.1, 51865
+    cfg = WhisperConfig.from_name("small", with_decoder=False)
+    m = AVNet("audiovisual", None, 96, MODELARGS, V, whisper_config=cfg, dtype=dtype)
+    sd = seed_module(m, 33)
+    sd = tame_residual_branches(m.visual_model, sd, "visual_model.")
+    m.to(dev).train(training)
+    batch = synthetic_batch(B=2, Tv=75, H=96, W=96, L=32, vocab=V, seed=19)
+    loss, ctc, ce, logits = m.training_step(to_device(batch, dev))
+    B, T, H, d = 2, 75, 8, 512
+    drop = None
+    if training:
+        drop = {"attn": [], "ff": []}
+        for i in range(3):
+            drop["attn"].append(torch.from_numpy(attn_keep_mask(m._dropout_seed(f"fusion.{i}.attn"), (B, H, T, T), p)))
+            drop["ff"].append(torch.from_numpy(keep_mask(m._dropout_seed(f"fusion.{i}.ff"), (B * T, d), p)).view(B, T, d))
+    loss_r, ctc_r, ce_r, logits_r, grads_r, _ = oracle.training_step(sd, batch, 12, 8, training=training, drop=drop,
+                                                                     p_drop=p if training else 0.0, masked_row="zero")
+    tol = TOL[dtype]
+    assert logits.shape == logits_r.shape == (2, 75, V)
+    assert max_err(logits, logits_r) < tol
+    assert abs(loss.item() - loss_r.item()) < tol * max(1.0, abs(loss_r.item()))
+    ids, ref_ids = m.decode_ids(logits).cpu(), logits_r.argmax(-1)
+    top2 = logits_r.topk(2, -1).values
+    sure = (top2[..., 0] - top2[..., 1]) > 2 * tol * logits_r.abs().max()
+    assert sure.any() and torch.equal(ids[sure], ref_ids[sure])
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k in ("decoder.linear.weight", "decoder.linear.bias", "fusion_module.layers.0.attn.in_proj_weight",
+              "fusion_module.layers.0.ff.0.weight", "fusion_module.layers.0.attn_ln.weight", "audio_proj.weight",
+              "video_proj.weight"):
+        gr = grads_r[k]
+        assert (params[k].grad.float().cpu() - gr).abs().max().item() < 5 * tol * max(1.0, gr.abs().max().item()), k

@@ -156,7 +156,7 @@ def test_conv_implicit_gemm(dev, dtype, cfg):
 
 @pytest.mark.parametrize("idt,odt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
                                      (torch.bfloat16, torch.bfloat16)])
-@pytest.mark.parametrize("D", [384, 512, 768, 1280])
+@pytest.mark.parametrize("D", [384, 512, 768, 1024, 1280])
 def test_layernorm_fwd_bwd(dev, idt, odt, D):
     g = torch.Generator().manual_seed(D)
     rows = 77
