@@ -74,10 +74,32 @@ def synthetic_batch(B, T, H, W, seed, dev, L=32, mel_frames=3000):
     return {k: v.to(dev) for k, v in batch.items()}
 
 
-def cpu_baseline(whisper, threads, budget_s=25.0):
-    """The CPU oracle's training step (forward + backward of the same network, fp32) on ONE clip."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_threads():
+    """Threads for the CPU leg: this process's CPU share.  The GPU boxes export OMP_NUM_THREADS = the share of one
+    GPU (16) while os.cpu_count() shows the whole machine; without that variable every visible core is used."""
+    try:
+        return max(1, int(os.environ["OMP_NUM_THREADS"]))
+    except (KeyError, ValueError):
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(whisper, threads, mode="train", budget_s=20.0):
+    """The CPU oracle's training step (forward + backward of the same network, fp32) on ONE clip, in the same
+    BatchNorm mode as the GPU number, plus BASELINE configuration 1 (Whisper-tiny encoder only, 4 x 10 s clips,
+    fp32) on the same cores."""
     import oracle
-    from mocov2_whisper_flamingo_amd import AVNet
+    from mocov2_whisper_flamingo_amd import AVNet, WhisperConfig, WhisperModel
     torch.set_num_threads(threads)
     m = AVNet("audiovisual", None, 96, MODELARGS, VOCAB, whisper_config=whisper, dtype=torch.float32)
     sd = {k: v.detach() for k, v in m.state_dict().items()}
@@ -88,7 +110,7 @@ def cpu_baseline(whisper, threads, budget_s=25.0):
     for i in range(4):
         b = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         t0 = time.perf_counter()
-        oracle.training_step(sd, b, heads, MODELARGS[1], training=False, masked_row="zero")
+        oracle.training_step(sd, b, heads, MODELARGS[1], training=mode == "train", masked_row="zero")
         dt = time.perf_counter() - t0
         if i > 0:
             times.append(dt)
@@ -96,9 +118,128 @@ def cpu_baseline(whisper, threads, budget_s=25.0):
             break
     times.sort()
     med = times[len(times) // 2]
+    # configuration 1: Whisper-tiny encoder, 4 clips of 10 s (mel zero-padded to 3000 frames), fp32
+    tiny = WhisperModel(WhisperConfig.from_name("tiny", with_decoder=False))
+    tsd = {k: v.detach() for k, v in tiny.state_dict().items()}
+    mel = torch.randn(4, 80, 3000, generator=torch.Generator().manual_seed(7))
+    mel[:, :, 1000:] = 0.0
+    t1 = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        oracle.whisper_encoder(tsd, "encoder.", mel, 6)
+        if i > 0:
+            t1.append(time.perf_counter() - t0)
+    t1.sort()
     return {"value": round(1.0 / med, 4), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": f"{len(times)} timed fwd+bwd steps of 1 clip (30 s audio + 75x96x96 video), fp32, eval-mode BN, "
-                      f"after 1 warm-up; median {med:.2f} s/step"}
+            "cpu_model": cpu_model_name(), "host_cpus_visible": os.cpu_count(),
+            "sample": f"{len(times)} timed fwd+bwd steps of 1 clip (30 s audio + 75x96x96 video), fp32, {mode}-mode BN "
+                      f"(no dropout draws), after 1 warm-up; median {med:.2f} s/step; threads = this process's CPU share",
+            "config1": {"value": round(4.0 / t1[len(t1) // 2], 3), "unit": "clips/s",
+                        "sample": f"Whisper-tiny encoder forward, 4 x 10 s mel clips, fp32, {len(t1)} timed passes after 1 "
+                                  f"warm-up; median {t1[len(t1) // 2] * 1e3:.0f} ms/pass"}}
+
+
+def _timed(fn, n=10, warm=3):
+    """Average seconds per call of ``fn`` from HIP events on the current stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / n
+
+
+def roofline_extra(dev):
+    """Rooflines of the kernels beside the dominant GEMM, each timed alone at the shapes it has in the step:
+    the encoder's attention forward (MFMA), the HBM-bound kernels (LayerNorm, batch-norm apply, the 3D stem, the
+    head losses) as algorithmic bytes / time against 8 TB/s, and the gated cross-attention block's two entry
+    points at the benchmark shape and at the reference's max_frames (B = 8, T = 400: 3200 rows)."""
+    from mocov2_whisper_flamingo_amd import GatedCrossAttentionBlock, ops
+    from mocov2_whisper_flamingo_amd import functional as Fn
+    bf = torch.bfloat16
+    out = {}
+    # encoder self-attention, one Whisper-small layer of the batch
+    B, H, T = 8, 12, 1500
+    qkv = torch.randn(B, T, 3 * H * 64, device=dev).to(bf)
+    t = _timed(lambda: ops.attn_fwd(qkv[:, :, :H * 64], qkv[:, :, H * 64:2 * H * 64], qkv[:, :, 2 * H * 64:], H,
+                                    scale=0.125, use_mfma=True))
+    fl = 4.0 * B * H * T * T * 64
+    out["attn_fwd_mfma_kernel"] = {"bound": "mfma", "shape": "B=8 H=12 T=1500 hd=64", "us": round(t * 1e6, 1),
+                                   "achieved": round(fl / t / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(fl / t / 1e12 / PEAK_BF16_TFLOPS, 4)}
+
+    def hbm(name, shape, nbytes, fn):
+        t = _timed(fn)
+        out[name] = {"bound": "hbm", "shape": shape, "us": round(t * 1e6, 1), "algorithmic_mb": round(nbytes / 1e6, 1),
+                     "achieved": round(nbytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(nbytes / t / 8e12, 4)}
+
+    x = torch.randn(12000, 768, device=dev)
+    g, b_ = torch.ones(768, device=dev), torch.zeros(768, device=dev)
+    hbm("layernorm_fwd_kernel", "12000 x 768 fp32 -> bf16", 12000 * 768 * 6, lambda: ops.layernorm_fwd(x, g, b_, out_dtype=bf))
+    raw = torch.randn(375000, 256, device=dev).to(bf)
+    sc, sh = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+    hbm("bn_apply_kernel", "375000 x 256 bf16 in place (layer1 bn3 without residual)", 375000 * 256 * 4,
+        lambda: ops.bn_apply(raw, sc, sh, relu=True, out=raw))
+    video = torch.randn(8, 75, 3, 96, 96, device=dev)
+    w = ops.stem_pack_weight(torch.randn(64, 3, 5, 3, 3, device=dev) * 0.1)
+    fr = ops.stem_pack_frags(w)
+    st = ops.stem_stats_slabs(video)
+    hbm("stem3d_mfma_kernel", "8 x 75 x 3 x 96 x 96 fp32 -> 600 x 50 x 50 x 64 bf16 (+ BN partial sums)",
+        video.numel() * 4 + 600 * 50 * 50 * 64 * 2, lambda: ops.stem3d_fwd(video, w, bf, col_stats=(st[0], st[1]), frags=fr))
+    ld = 51872
+    buf = torch.randn(600, ld, device=dev)
+    logits = buf.view(8, 75, ld)[:, :, :VOCAB]
+    tg = torch.randint(1, VOCAB, (8, 32), device=dev)
+    il, tl = torch.full((8,), 75, device=dev), torch.full((8,), 32, device=dev)
+    _, ws = ops.head_loss_fwd(logits, tg, il, tl)
+    hbm("head_loss_fwd (row_lse + ce + ctc)", "600 x 51865 fp32 logits", 600 * VOCAB * 4, lambda: ops.head_loss_fwd(logits, tg, il, tl))
+    hbm("head_loss_bwd (dlogits in bf16)", "600 x 51865 fp32 logits -> bf16 gradient", 600 * VOCAB * 6,
+        lambda: ops.head_loss_bwd(logits, tg, il, tl, ws, bf, ld_out=ld))
+    # gated cross-attention block through its two entry points (d 512, 8 heads, dropout 0.1, ragged key mask)
+    d, Hh = 512, 8
+    blk = GatedCrossAttentionBlock(d, Hh, dropout=0.1).to(dev).train()
+    with torch.no_grad():
+        blk.attn_gate.fill_(0.5)
+        blk.ff_gate.fill_(0.5)
+    blk._cache = Fn.WeightCache(bf)
+    blk._seed_fn = lambda tag: 99
+    for p_ in blk.parameters():
+        p_.grad = torch.zeros_like(p_)
+        p_._avsr_direct_grad = True
+    xb = {}
+    for Bx, Tx in ((8, 75), (8, 400)):
+        xq = torch.randn(Bx, Tx, d, device=dev).to(bf).requires_grad_(True)
+        xa = torch.randn(Bx, Tx, d, device=dev).to(bf).requires_grad_(True)
+        mask = torch.zeros(Bx, Tx, dtype=torch.bool, device=dev)
+        mask[:, Tx - Tx // 8:] = True
+        dout = torch.randn(Bx, Tx, d, device=dev).to(bf)
+        rows = Bx * Tx
+        gemm = rows * (2 * d * d + 2 * d * d + 16 * d * d) + rows * 4 * d * d
+        attn = 4 * Bx * Hh * Tx * Tx * 64
+
+        def fwd():
+            with torch.no_grad():
+                blk(xq, xa, mask)
+
+        def fwdbwd():
+            blk(xq, xa, mask).backward(dout)
+            xq.grad = xa.grad = None
+
+        tf = _timed(fwd, n=20)
+        tb = _timed(fwdbwd, n=20) - tf
+        ff, fb = gemm + attn, 2 * gemm + 2.5 * attn
+        xb[f"B={Bx} T={Tx} ({rows} rows)"] = {
+            "fwd_us": round(tf * 1e6, 1), "fwd_tflops": round(ff / tf / 1e12, 1), "fwd_frac_of_mfma_peak": round(ff / tf / 2.5e15, 4),
+            "bwd_us": round(tb * 1e6, 1), "bwd_tflops": round(fb / tb / 1e12, 1), "bwd_frac_of_mfma_peak": round(fb / tb / 2.5e15, 4)}
+    out["avsr_gated_xattn_fwd / _bwd (one block)"] = {
+        "bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "shapes": xb,
+        "note": "wall time per call incl. host enqueue (the small shape is launch bound); counter-based MFMA-busy per "
+                "kernel: profiles/r02_xattn_pmc_*.json"}
+    return out
 
 
 def main():
@@ -128,6 +269,7 @@ def main():
                          "the pipeline (with it, the step time then hinges on which hardware queue that stream lands on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-roofline-extra", action="store_true", help="skip the per-kernel rooflines beside the GEMM's")
     args = ap.parse_args()
 
     if os.environ.get("AVSR_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
@@ -269,9 +411,37 @@ def main():
                     "algorithmic_gflop_per_step": round(fsum / 1e9, 1),
                     "kernel_time_share_of_step": round(tsum / (dt / args.steps), 3)}
 
+    extra = None
+    if not args.no_roofline and rank == 0 and not args.no_roofline_extra:
+        extra = roofline_extra(dev)
+
+    # the data-parallel term: the gradient all-reduce alone (the flat fp32 gradient buffer, bucket by bucket as the
+    # step issues it), against the 7 x 153 GB/s of xGMI links a GPU has
+    dp_term = None
+    if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "nccl":
+        nbytes = trainer.flat_grad.numel() * 4
+
+        def allreduce():
+            for bk in trainer.buckets:
+                lo, hi = bk["range"]
+                dist.all_reduce(trainer.flat_grad[lo:hi])
+
+        barrier()
+        t_ar = _timed(allreduce, n=10, warm=3)
+        tt = torch.tensor([t_ar], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_ar = tt.item()
+        trainer.flat_grad.zero_()
+        dp_term = {"rccl_ranks": world, "gradient_mb": round(nbytes / 1e6, 1), "buckets": len(trainer.buckets),
+                   "allreduce_ms": round(t_ar * 1e3, 3),
+                   "bus_gbps": round(2 * (world - 1) / world * nbytes / t_ar / 1e9, 1), "xgmi_peak_gbps": 7 * 153,
+                   "share_of_step": round(t_ar / (dt / args.steps), 3),
+                   "note": "all-reduce timed alone after the run; in the step it is issued in stream order after "
+                           "backward and runs beside the next batch's frozen encoders"}
+
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        cpu = cpu_baseline(args.whisper, threads=min(16, os.cpu_count() or 1))
+        cpu = cpu_baseline(args.whisper, threads=host_threads(), mode=args.mode)
 
     if rank == 0:
         clips = B * world * args.steps
@@ -286,7 +456,7 @@ def main():
                                    + "fwd+bwd+all-reduce+clip+AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
                        "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 3)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "roofline_extra": extra, "dp": dp_term,
         }
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

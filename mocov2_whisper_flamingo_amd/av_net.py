@@ -80,6 +80,9 @@ class AVNet(nn.Module):
         self.decoder._cache = self._cache
         self._seed, self._step = int(seed), 0
         self.overlap_encoders = True        # run the visual frontend on a second stream next to the audio encoder
+        # the last encoder layer computes queries / MLP / final norm only for the frames the truncation keeps
+        # (identical results; see WhisperEncoder.forward)
+        self.prune_unread_frames = True
         self._side = None
         self._aside = None
         self._graphs = {}
@@ -152,7 +155,11 @@ class AVNet(nn.Module):
                 if not channels_last:
                     audioBatch, channels_last = ops.transpose2d(audioBatch, dtype=cdt), True
                 audioBatch = audioBatch.contiguous().view(audioBatch.shape[0] * windows, 3000, 80)
-            enc = self.whisper_model.encoder(audioBatch, attention_mask=None, dtype=cdt, channels_last=channels_last)[0]
+            # only the first min(1500, T_video) encoder frames survive the truncation of models/av_net.py:91-96
+            n_video = videoBatch.shape[2] if (videoBatch.dim() == 6 and videoBatch.shape[1] == 1) else videoBatch.shape[1]
+            keep = n_video if (self.prune_unread_frames and windows == 1) else None
+            enc = self.whisper_model.encoder(audioBatch, attention_mask=None, dtype=cdt, channels_last=channels_last,
+                                             rows=keep)[0]
             if windows > 1:
                 enc = enc.view(enc.shape[0] // windows, windows * enc.shape[1], enc.shape[2])
         if side is None:
@@ -191,6 +198,7 @@ class AVNet(nn.Module):
     def _encode_graph(self, inputBatch, ahead):
         audioBatch, _, videoBatch, _, videoLen = inputBatch
         key = (tuple(audioBatch.shape), audioBatch.dtype, tuple(videoBatch.shape), videoBatch.dtype, self.training,
+               self.prune_unread_frames,
                self.visual_model.training, self.compute_dtype, self.long_form, self.whisper_model.encoder.attn_fp8,
                sum(p._version for p in self.whisper_model.encoder.parameters()),
                sum(p._version for p in self.visual_model.parameters()), torch.cuda.current_device())

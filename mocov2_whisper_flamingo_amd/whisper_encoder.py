@@ -135,13 +135,20 @@ class WhisperEncoder(nn.Module):
 
     # ---- forward ----------------------------------------------------------
     @torch.no_grad()
-    def forward(self, input_features, attention_mask=None, dtype=torch.bfloat16, channels_last=False, attn_fp8=None):
+    def forward(self, input_features, attention_mask=None, dtype=torch.bfloat16, channels_last=False, attn_fp8=None,
+                rows=None):
         """input_features: [B, n_mels, 3000] (the HF layout) or, with
         ``channels_last``, [B, 3000, n_mels].  ``attention_mask`` is accepted and
         ignored exactly as the HF encoder does (hf:607-609).  Returns a 1-tuple
         ``([B, 1500, D] in the compute dtype,)`` so that ``encoder(x)[0]`` works.
         ``attn_fp8`` (default: the module's ``attn_fp8`` attribute): QK^T and PV of the self-attention
-        on fp8 e4m3 MFMA (bf16 compute dtype only); everything else stays bf16."""
+        on fp8 e4m3 MFMA (bf16 compute dtype only); everything else stays bf16.
+        ``rows`` = n < 1500: the caller reads only the first n frames of every clip (AVNet truncates the audio
+        features to the video length, models/av_net.py:91-96) and gets ``[B, n, D]``, bit for bit the first n
+        frames of the full result: every layer but the last runs on all 1500 frames (its keys and values feed
+        the kept frames' attention); in the last layer only keys and values are computed for all frames, while
+        queries, attention output, out-projection, MLP and the final LayerNorm - all row-wise - run on the n
+        kept frames."""
         cfg = self.cfg
         x = input_features
         if not channels_last:
@@ -179,8 +186,22 @@ class WhisperEncoder(nn.Module):
             if not use_mfma:
                 raise ValueError("fp8 attention needs the bf16 compute dtype")
             use_mfma = "fp8"
-        for lw in pk["layers"]:
+        n_keep = Tn if rows is None else max(1, min(int(rows), Tn))
+        for li, lw in enumerate(pk["layers"]):
             h = ops.layernorm_fwd(xs, *lw["ln1"], out_dtype=dtype)
+            if n_keep < Tn and li == len(pk["layers"]) - 1:
+                kv = ops.gemm_nt(h, lw["wqkv"][D:], bias=lw["bqkv"][D:]).view(B, Tn, 2 * D)
+                q = ops.gemm_nt(h.view(B, Tn, D)[:, :n_keep], lw["wqkv"][:D], bias=lw["bqkv"][:D])      # [B, n, D]
+                o = ops.attn_fwd(q, kv[:, :, :D], kv[:, :, D:], H, scale=1.0, use_mfma=use_mfma)
+                xk = torch.empty((B, n_keep * D), dtype=torch.float32, device=x.device)                 # kept rows of the stream
+                ops.cast_rows(xs.view(B, Tn * D)[:, :n_keep * D], xk)
+                xs = xk.view(B * n_keep, D)
+                ops.gemm_nt(o.view(B * n_keep, D), lw["wo"], bias=lw["bo"], residual=xs, out=xs)
+                h = ops.layernorm_fwd(xs, *lw["ln2"], out_dtype=dtype)
+                f = ops.gemm_nt(h, lw["wfc1"], bias=lw["bfc1"], act=ops.ACT_GELU)
+                ops.gemm_nt(f, lw["wfc2"], bias=lw["bfc2"], residual=xs, out=xs)
+                Tn = n_keep
+                break
             qkv = ops.gemm_nt(h, lw["wqkv"], bias=lw["bqkv"]).view(B, Tn, 3 * D)
             o = ops.attn_fwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H, scale=1.0, use_mfma=use_mfma)
             ops.gemm_nt(o.view(B * Tn, D), lw["wo"], bias=lw["bo"], residual=xs, out=xs)

@@ -202,3 +202,29 @@ def test_config5_large_v2_long_form(dev, attention, tol):
              batch["video_lengths"].clone().to(dev)))
     assert got.shape == ref.shape == (1, 150, V)
     assert max_err(got, ref) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unread_frames_pruned_in_the_last_encoder_layer(dev, dtype):
+    """encoder(..., rows=n) returns bit for bit the first n frames of the full output (only the last layer's
+    row-wise work on the frames nobody reads is skipped), and AVNet's logits do not change when it uses it."""
+    cfg = WhisperConfig.from_name("tiny", with_decoder=False)
+    m = WhisperModel(cfg)
+    seed_module(m, 7)
+    m.to(dev)
+    mel = torch.randn(2, 3000, 80, generator=torch.Generator().manual_seed(3)).to(dev)
+    full = m.encoder(mel, dtype=dtype, channels_last=True)[0]
+    for n in (1, 75, 400, 1499):
+        part = m.encoder(mel, dtype=dtype, channels_last=True, rows=n)[0]
+        assert part.shape == (2, n, cfg.d_model)
+        assert torch.equal(part, full[:, :n]), n
+    assert torch.equal(m.encoder(mel, dtype=dtype, channels_last=True, rows=5000)[0], full)
+    net = AVNet("audiovisual", None, 96, (128, 2, 4, 3000, 512, 0.1), 503, whisper_config=MICRO, dtype=dtype)
+    seed_module(net, 21)
+    net.to(dev).eval()
+    bd = to_device(synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=5), dev)
+    outs = []
+    for prune in (True, False):
+        net.prune_unread_frames = prune
+        outs.append(net((bd["audio"], bd["audio_mask"], bd["video"], bd["video_mask"], bd["video_lengths"].clone())))
+    assert torch.equal(outs[0], outs[1])
