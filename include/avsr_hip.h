@@ -85,7 +85,10 @@ typedef struct {
      * order after scale / bias:  pre[m,n] = v (a second output of out_dtype: the value BEFORE the activation and
      * the gate);  v = act(v);  v *= gelu'(mul_gelu_grad_of[m,n]) (backward through a GELU whose input was saved);
      * v = dropout(v) with keep decision generator(seed, m*N + n), kept values scaled by 1/(1-p_drop);
-     * then the residual / gate step above. */
+     * then the residual / gate step above.
+     * C == NULL (bf16 inputs, col_sum / col_sumsq given, no residual): a statistics-only pass - the launch
+     * fills the column-sum slabs and stores no product (batch statistics of a convolution whose output is
+     * cheaper to recompute with the normalisation folded in than to store raw and re-read). */
     void* pre; int64_t ldp;
     const void* mul_gelu_grad_of; int64_t ld_aux;
     float p_drop;

@@ -257,6 +257,9 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                     }
                 }
             }
+            if constexpr (EXT) {
+                if (p.C == nullptr) continue;   // statistics-only pass: the column sums are all this launch produces
+            }
             OutT* cp = (OutT*)p.C + cbase + (long)m * p.ldc + n;
             const OutT* rp = has_res ? (const OutT*)p.res + (long)(p.res_period > 0 ? m % p.res_period : m) * p.ldr + n : nullptr;
             if (full) {
@@ -770,7 +773,9 @@ extern "C" int64_t avsr_gemm_stats_parts(int in_dtype, int64_t M) {
 }
 
 extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
-    if (!g || !g->A || !g->B || !g->C) return AVSR_EINVAL;
+    if (!g || !g->A || !g->B) return AVSR_EINVAL;
+    // C == NULL: a statistics-only pass (column sums without the product itself; dense bf16 products only)
+    if (!g->C && !(g->col_sum && g->in_dtype == AVSR_BF16 && !g->pre && !g->residual)) return AVSR_EINVAL;
     if (g->M <= 0 || g->N <= 0 || g->K <= 0 || g->batch <= 0) return AVSR_EINVAL;
     if (g->M > 0x7fffffff || g->N > 0x7fffffff || g->K > 0x7fffffff) return AVSR_EUNSUPPORTED;
     if (g->in_dtype != AVSR_F32 && g->in_dtype != AVSR_BF16) return AVSR_EINVAL;
@@ -809,7 +814,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     p.stride = g->conv.stride; p.pad_h = g->conv.pad_h; p.pad_w = g->conv.pad_w; p.OH = g->conv.OH; p.OW = g->conv.OW;
     p.pre = g->pre; p.ldp = g->ldp; p.aux = g->mul_gelu_grad_of; p.ldaux = g->ld_aux;
     p.p_drop = g->p_drop; p.seed = g->seed;
-    p.ext = (g->pre || g->mul_gelu_grad_of || g->p_drop > 0.f) ? 1 : 0;
+    p.ext = (g->pre || g->mul_gelu_grad_of || g->p_drop > 0.f || !g->C) ? 1 : 0;
     if (p.ext) {
         const size_t osz_ = g->out_dtype == AVSR_BF16 ? 2 : 4;
         if ((!g->pre || (aligned_to(g->pre, 16) && (g->ldp * osz_) % 16 == 0)) &&

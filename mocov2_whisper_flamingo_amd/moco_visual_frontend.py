@@ -12,6 +12,7 @@ one finalize + one in-place apply kernel per BN, running statistics updated in
 place (the statistics come from the fp32 accumulators, before rounding).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -72,6 +73,7 @@ class MoCoVisualFrontend(nn.Module):
         )
         self.MoCoModel = _ResNet50Trunk()
         self.compute_dtype = torch.bfloat16
+        self.two_pass_min_bytes = int(os.environ.get("AVSR_TWO_PASS_MIN_BYTES", 1 << 60))   # see _conv_bn
         self._packed = None
         self._blocks = list(self.MoCoModel.blocks())
 
@@ -119,8 +121,27 @@ class MoCoVisualFrontend(nn.Module):
         C = w.shape[0]
         rows = ops.conv_out_rows(x, k, k, stride, pad)
         stats = ops.gemm_stats_slabs(rows, C, x.dtype, x.device)
-        raw = ops.conv_nhwc(x, w, k, k, stride, pad, col_stats=(stats[0], stats[1]))
         aff = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        # Option (off unless two_pass_min_bytes is lowered): expanding 1x1 convolutions with a short reduction
+        # (layer1's conv3 / downsample: 64 -> 256 channels over 375 000 pixels) are bound by the 192 MB output
+        # they store.  Instead of storing the raw output and re-reading it for the normalisation, run the product
+        # twice: a first pass that only accumulates the column sums (no store), then the product again with scale /
+        # shift, ReLU and the residual in its epilogue.  Same sums (same tiles, same fp32 accumulators), one
+        # rounding less.  Measured in the whole step it does not pay (7.87 ms against 7.81 ms without): the
+        # normalisation pass is pure HBM traffic that overlaps with the audio encoder's MFMA-bound kernels, the
+        # second product is not.
+        if (k == 1 and stride == 1 and pad == 0 and x.dtype == torch.bfloat16 and residual_affine is None
+                and C >= 4 * w.shape[1] and rows * C * 2 >= self.two_pass_min_bytes):
+            ops.conv_nhwc(x, w, 1, 1, 1, 0, col_stats=(stats[0], stats[1]), stats_only=True)
+            ops.bn_finalize(stats[0], stats[1], rows, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                            bn.running_var, aff[0], aff[1], bn.eps, bn.momentum)
+            if residual is not None:
+                act, res2d = ops.ACT_RELU_AFTER_RESIDUAL, residual.view(-1, residual.shape[-1])
+            else:
+                act, res2d = (ops.ACT_RELU if relu else ops.ACT_NONE), None
+            out = ops.conv_nhwc(x, w, 1, 1, 1, 0, scale=aff[0], bias=aff[1], act=act, residual=res2d)
+            return (out, None) if defer else out
+        raw = ops.conv_nhwc(x, w, k, k, stride, pad, col_stats=(stats[0], stats[1]))
         ops.bn_finalize(stats[0], stats[1], rows, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                         bn.running_var, aff[0], aff[1], bn.eps, bn.momentum)
         if defer:

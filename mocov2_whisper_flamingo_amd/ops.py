@@ -40,9 +40,10 @@ def _need_cuda(*ts):
 
 
 def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NONE, residual=None,
-            res_period=0, gate=None, alpha=1.0, col_stats=None, conv=None, M=None):
+            res_period=0, gate=None, alpha=1.0, col_stats=None, conv=None, M=None, stats_only=False):
     """out[m,n] = epi(sum_k a[m,k] b[n,k]).  a: [M,K] or [batch,M,K]; b: [N,K] or [batch,N,K].
-    conv = (H, W, C, KH, KW, stride, pad_h, pad_w, OH, OW): a is an NHWC image batch, M = n_img*OH*OW."""
+    conv = (H, W, C, KH, KW, stride, pad_h, pad_w, OH, OW): a is an NHWC image batch, M = n_img*OH*OW.
+    ``stats_only``: fill ``col_stats`` and store no product (returns None)."""
     lib = _lib.load()
     _need_cuda(a, b, out, bias, scale, residual, gate)
     d = GemmDesc()
@@ -69,20 +70,23 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
     if batched and b.shape[0] != batch:
         raise ValueError("batch mismatch")
     odt = out_dtype if out_dtype is not None else (out.dtype if out is not None else a.dtype)
-    if out is None:
+    if stats_only:
+        if col_stats is None or out is not None or residual is not None:
+            raise ValueError("a statistics-only product takes col_stats and neither out nor residual")
+    elif out is None:
         shape = (batch, Mv, N) if (a.dim() == 3 and conv is None) else (Mv, N)
         out = torch.empty(shape, dtype=odt, device=a.device)
-    if out.stride(-1) != 1:
+    if out is not None and out.stride(-1) != 1:
         raise ValueError("out must be row-major")
-    d.in_dtype, d.out_dtype = _dt(a), _DT[out.dtype]
+    d.in_dtype, d.out_dtype = _dt(a), _DT[odt if out is None else out.dtype]
     if b.dtype != a.dtype:
         raise TypeError("a and b dtypes differ")
     d.M, d.N, d.K = Mv, N, K
     d.A, d.lda, d.B, d.ldb = a.data_ptr(), lda, b.data_ptr(), b.stride(-2)
-    d.C, d.ldc = out.data_ptr(), out.stride(-2)
+    d.C, d.ldc = (None, N) if out is None else (out.data_ptr(), out.stride(-2))
     d.batch, d.strideA = batch, sA
     d.strideB = b.stride(0) if batched else 0
-    d.strideC = out.stride(0) if out.dim() == 3 else 0
+    d.strideC = out.stride(0) if (out is not None and out.dim() == 3) else 0
     d.alpha = alpha
     d.scale, d.bias, d.act = _p(scale), _p(bias), act
     if residual is not None:
@@ -149,7 +153,7 @@ def conv_nhwc(x, w, KH, KW, stride, pad, **kw):
     OH = (H + 2 * ph - KH) // stride + 1
     OW = (W + 2 * pw - KW) // stride + 1
     y = gemm_nt(x, w, conv=(H, W, C, KH, KW, stride, ph, pw, OH, OW), **kw)
-    return y.view(n, OH, OW, w.shape[0])
+    return None if y is None else y.view(n, OH, OW, w.shape[0])
 
 
 def layernorm_fwd(x, gamma, beta, *, out_dtype=None, add=None, save_stats=False, eps=1e-5):
