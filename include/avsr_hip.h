@@ -293,10 +293,19 @@ int avsr_avgpool_mask_fwd(avsr_stream_t stream, int in_dtype, int out_dtype, con
  * bilinear resize (interpolate align_corners=False, :66-68; OH=H, OW=W copies), /255, horizontal flip of the
  * clips with flip[b] != 0 (:70), frames with frame_zero[b*T+t] != 0 zeroed (AdaptiveTimeMask, :27-45,73), then
  * (x - mean[c]) / std[c] (:74,95).  flip / frame_zero: device uint8, may be NULL; mean3 / std3: HOST float[3].
- * The random draws are the host's; ColorJitter / RandomGrayscale (:71-72) are not part of it. */
+ * The random draws are the host's; ColorJitter / RandomGrayscale (:71-72) are avsr_video_color. */
 int avsr_video_preprocess(avsr_stream_t stream, int in_is_u8, const void* video, float* out, int64_t B, int64_t T,
                           int64_t H, int64_t W, int64_t OH, int64_t OW, const uint8_t* flip,
                           const uint8_t* frame_zero, const float* mean3, const float* std3);
+/* The colour steps of the training VideoTransform (datamodule/transforms.py:71-74) on frames already scaled to
+ * [0, 1] (avsr_video_preprocess with mean 0 / std 1), in place on video fp32 [B,T,3,H,W]: torchvision ColorJitter
+ * (per clip: order int32 [B,4] = the drawn permutation of 0 brightness, 1 contrast, 2 saturation, 3 hue, a negative
+ * entry skips a step, order == NULL skips all; factors fp32 [B,4] = brightness, contrast, saturation factors and the
+ * hue shift), RandomGrayscale (grey uint8 [B], may be NULL), AdaptiveTimeMask (frame_zero uint8 [B*T], may be NULL)
+ * and Normalize (mean3 / std3: HOST float[3]).  The random draws are the host's.  3*H*W*4 bytes <= 150 KiB. */
+int avsr_video_color(avsr_stream_t stream, float* video, int64_t B, int64_t T, int64_t H, int64_t W,
+                     const int32_t* order, const float* factors, const uint8_t* grey, const uint8_t* frame_zero,
+                     const float* mean3, const float* std3);
 /* sum / sumsq: [nparts, C] partial-sum slabs; ws: avsr_bn_finalize_workspace_floats(C) floats, needed when
  * nparts > 8192.  Optional for 512 <= nparts <= 8192: with ws AND tickets (device int32, ceil(C/64) values, all
  * zero on entry; the kernel leaves them zero) the slab rows are split over up to 16 workgroups per 64 channels

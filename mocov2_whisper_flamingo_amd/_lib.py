@@ -75,6 +75,7 @@ SIGNATURES = {
     "avsr_logmel_fwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "avsr_logmel_fwd_static": (_i32, [_vp, _i32, _i32, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
     "avsr_video_preprocess": (_i32, [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "avsr_video_color": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avsr_logmel_augment_workspace_floats": (_i64, [_i64, _i64]),
     "avsr_logmel_augment_fwd": (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp,
                                         _vp, _i64, _vp, _i64, _vp, _i64, _vp]),

@@ -425,6 +425,91 @@ __global__ __launch_bounds__(256) void video_preprocess_kernel(const TI* __restr
     }
 }
 
+// ColorJitter + RandomGrayscale + AdaptiveTimeMask + Normalize of the training transform (datamodule/transforms.py:71-74)
+// on frames in [0, 1]: one workgroup per frame, the frame's three planes in LDS.  The four jitter steps run in the
+// clip's drawn order (torchvision ColorJitter.forward: 0 brightness, 1 contrast, 2 saturation, 3 hue; a negative
+// entry skips the step), each as torchvision's functional_tensor ops define it: blend(img, other, f) =
+// clamp(f*img + (1-f)*other, 0, 1) with other = 0 (brightness), the frame's mean grey level (contrast), the pixel's
+// grey level 0.2989 r + 0.587 g + 0.114 b (saturation); hue = RGB -> HSV, h = (h + shift) mod 1, HSV -> RGB.
+__device__ __forceinline__ float grey_of(float r, float g, float b) { return 0.2989f * r + 0.587f * g + 0.114f * b; }
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+__global__ __launch_bounds__(256) void video_color_kernel(float* __restrict__ x, int T, int HW, const int* __restrict__ order,
+                                                          const float* __restrict__ factors, const uint8_t* __restrict__ grey,
+                                                          const uint8_t* __restrict__ frame_zero, float m0, float m1, float m2,
+                                                          float i0, float i1, float i2) {
+    extern __shared__ float plane[];            // [3][HW]
+    __shared__ float red[16];
+    const int f = blockIdx.x, b = f / T, tid = threadIdx.x;
+    float* xf = x + (long)f * 3 * HW;
+    if (frame_zero && frame_zero[f]) {          // AdaptiveTimeMask zeroes the frame after the colour steps
+        for (int i = tid; i < HW; i += 256) {
+            xf[i] = (0.f - m0) * i0; xf[HW + i] = (0.f - m1) * i1; xf[2 * HW + i] = (0.f - m2) * i2;
+        }
+        return;
+    }
+    for (int i = tid; i < 3 * HW; i += 256) plane[i] = xf[i];
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+        const int op = order ? order[b * 4 + k] : -1;
+        if (op < 0 || op > 3) continue;
+        const float fac = factors[b * 4 + op];
+        if (op == 0) {
+            for (int i = tid; i < 3 * HW; i += 256) plane[i] = clamp01(fac * plane[i]);
+        } else if (op == 1) {
+            float acc = 0.f;
+            for (int i = tid; i < HW; i += 256) acc += grey_of(plane[i], plane[HW + i], plane[2 * HW + i]);
+            const float mean = block_sum(acc, red) / (float)HW;
+            for (int i = tid; i < 3 * HW; i += 256) plane[i] = clamp01(fac * plane[i] + (1.f - fac) * mean);
+        } else if (op == 2) {
+            for (int i = tid; i < HW; i += 256) {
+                const float l = grey_of(plane[i], plane[HW + i], plane[2 * HW + i]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) plane[c * HW + i] = clamp01(fac * plane[c * HW + i] + (1.f - fac) * l);
+            }
+        } else {
+            for (int i = tid; i < HW; i += 256) {
+                const float r = plane[i], g = plane[HW + i], bl = plane[2 * HW + i];
+                const float maxc = fmaxf(r, fmaxf(g, bl)), minc = fminf(r, fminf(g, bl));
+                const bool eq = maxc == minc;
+                const float cr = maxc - minc;
+                const float sat = cr / (eq ? 1.f : maxc);
+                const float div = eq ? 1.f : cr;
+                const float rc = (maxc - r) / div, gc = (maxc - g) / div, bc = (maxc - bl) / div;
+                float h = 0.f;
+                if (maxc == r) h = bc - gc;
+                else if (maxc == g) h = 2.f + rc - bc;
+                else h = 4.f + gc - rc;
+                h = fmodf(h / 6.f + 1.f, 1.f);
+                h = h + fac;
+                h = h - floorf(h);              // python's % 1.0: result in [0, 1)
+                const float h6 = h * 6.f, fi = floorf(h6), fr = h6 - fi;
+                int sector = (int)fi % 6;
+                if (sector < 0) sector += 6;
+                const float v = maxc;
+                const float pp = clamp01(v * (1.f - sat)), qq = clamp01(v * (1.f - sat * fr));
+                const float tt = clamp01(v * (1.f - sat * (1.f - fr)));
+                float ro, go, bo;
+                switch (sector) {
+                    case 0: ro = v; go = tt; bo = pp; break;
+                    case 1: ro = qq; go = v; bo = pp; break;
+                    case 2: ro = pp; go = v; bo = tt; break;
+                    case 3: ro = pp; go = qq; bo = v; break;
+                    case 4: ro = tt; go = pp; bo = v; break;
+                    default: ro = v; go = pp; bo = qq; break;
+                }
+                plane[i] = ro; plane[HW + i] = go; plane[2 * HW + i] = bo;
+            }
+        }
+        __syncthreads();
+    }
+    const bool to_grey = grey && grey[b];
+    for (int i = tid; i < HW; i += 256) {
+        float r = plane[i], g = plane[HW + i], bl = plane[2 * HW + i];
+        if (to_grey) r = g = bl = grey_of(r, g, bl);
+        xf[i] = (r - m0) * i0; xf[HW + i] = (g - m1) * i1; xf[2 * HW + i] = (bl - m2) * i2;
+    }
+}
+
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void avgpool_mask_kernel(const T* __restrict__ x, TO* __restrict__ y,
                                                            const int64_t* __restrict__ lens, int Tn, int HW, int C) {
@@ -593,6 +678,25 @@ extern "C" int avsr_video_preprocess(avsr_stream_t stream, int in_is_u8, const v
         hipLaunchKernelGGL(video_preprocess_kernel<float>, grid, block, 0, s, (const float*)video, out, n, (int)T, (int)H,
                            (int)W, (int)OH, (int)OW, flip, frame_zero, mean3[0], mean3[1], mean3[2], 1.f / std3[0],
                            1.f / std3[1], 1.f / std3[2]);
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_video_color(avsr_stream_t stream, float* video, int64_t B, int64_t T, int64_t H, int64_t W,
+                                const int32_t* order, const float* factors, const uint8_t* grey,
+                                const uint8_t* frame_zero, const float* mean3, const float* std3) {
+    if (!video || !mean3 || !std3 || B <= 0 || T <= 0 || H <= 0 || W <= 0 || (order && !factors)) return AVSR_EINVAL;
+    if (std3[0] == 0.f || std3[1] == 0.f || std3[2] == 0.f) return AVSR_EINVAL;
+    const size_t lds = (size_t)3 * H * W * sizeof(float);
+    if (lds > 150 * 1024 || B * T > 0x7fffffff) return AVSR_EUNSUPPORTED;       // a frame's three planes live in LDS
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)video_color_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
+            hipSuccess) return AVSR_EHIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(video_color_kernel, dim3((unsigned)(B * T)), dim3(256), lds, (hipStream_t)stream, video, (int)T,
+                       (int)(H * W), order, factors, grey, frame_zero, mean3[0], mean3[1], mean3[2], 1.f / std3[0],
+                       1.f / std3[1], 1.f / std3[2]);
     return avsr_launch_status();
 }
 

@@ -366,6 +366,25 @@ def video_preprocess(video, *, size=None, flip=None, frame_zero=None, mean=(0.48
     return out
 
 
+def video_color(video, *, order=None, factors=None, grey=None, frame_zero=None, mean=(0.485, 0.456, 0.406),
+                std=(0.229, 0.224, 0.225)):
+    """In place on video fp32 [B,T,3,H,W] with values in [0, 1]: ColorJitter steps in the drawn order (int32 [B,4],
+    factors fp32 [B,4]), RandomGrayscale (uint8 [B]), zeroed frames (uint8 [B,T]), normalisation."""
+    lib = _lib.load()
+    _need_cuda(video, order, factors, grey, frame_zero)
+    if video.dim() != 5 or video.shape[2] != 3 or not video.is_contiguous() or video.dtype != torch.float32:
+        raise ValueError("video must be a contiguous fp32 [B,T,3,H,W] tensor")
+    B, T, _, H, W = video.shape
+    for t_, dt_, shp in ((order, torch.int32, (B, 4)), (factors, torch.float32, (B, 4)), (grey, torch.uint8, (B,)),
+                         (frame_zero, torch.uint8, (B, T))):
+        if t_ is not None and (t_.dtype != dt_ or tuple(t_.shape) != shp or not t_.is_contiguous()):
+            raise ValueError("order int32 [B,4], factors fp32 [B,4], grey uint8 [B], frame_zero uint8 [B,T], contiguous")
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    check(lib.avsr_video_color(_stream(), video.data_ptr(), B, T, H, W, _p(order), _p(factors), _p(grey), _p(frame_zero),
+                               ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p)), "avsr_video_color")
+    return video
+
+
 def maxpool3x3s2(x, *, scale=None, shift=None, out_dtype=None):
     lib = _lib.load()
     N, H, W, C = x.shape

@@ -32,3 +32,4 @@ from .ref_whisper import whisper_encoder, whisper_decoder
 from .ref_visual import visual_frontend
 from .ref_avnet import avnet_forward, ctc_ce_loss, training_step, make_padding_mask
 from .ref_logmel import whisper_logmel, torchaudio_melspec_norm, torchaudio_melspec_train
+from .ref_video import video_transform_train, color_jitter

@@ -686,6 +686,36 @@ def test_video_transform(dev):
 
 
 @pytest.mark.gpu
+def test_video_transform_colour_steps(dev):
+    """The train pipeline with ColorJitter and RandomGrayscale (datamodule/transforms.py:65-75) against the CPU
+    restatement with fixed draws: every permutation position, skipped steps, a grey clip, zeroed frames, flips.
+    PARITY UNPINNED (torchvision absent): the restatement follows torchvision 0.19.1's tensor ops."""
+    import random
+    from mocov2_whisper_flamingo_amd import VideoTransform
+    g = torch.Generator().manual_seed(15)
+    B, T, H, W = 4, 6, 80, 72
+    u8 = torch.randint(0, 256, (B, T, 3, H, W), generator=g, dtype=torch.uint8)
+    u8[3, :, :, :10] = 77                                        # grey pixels (max == min) exercise the hue edge case
+    flips = [True, False, True, False]
+    zeros = [[t in (1, 4) for t in range(T)], [False] * T, [t == 0 for t in range(T)], [False] * T]
+    orders = [[3, 0, 2, 1], [1, 2, 3, 0], [0, -1, 3, -1], [2, 1, 0, 3]]
+    facs = [[1.4, 0.6, 1.3, 0.1], [0.6, 1.4, 0.7, -0.1], [1.1, 1.0, 1.0, 0.05], [0.9, 1.2, 0.0, -0.03]]
+    greys = [False, True, False, False]
+    got = VideoTransform("train")(u8.to(dev), draws=(flips, zeros, orders, facs, greys))
+    assert got.shape == (B, T, 3, 64, 64)
+    for b in range(B):
+        ref = oracle.video_transform_train(u8[b].float(), flips[b], orders[b], facs[b], greys[b], zeros[b])
+        # hue: a sector boundary (floor(6h)) can flip on a rounding difference; allow a handful of such pixels
+        diff = (got[b].cpu() - ref).abs()
+        assert diff.max() < 5e-2 and (diff > 1e-3).float().mean() < 1e-3, (b, float(diff.max()))
+    out = VideoTransform("train")(u8.to(dev), rng=random.Random(4))
+    assert out.shape == (B, T, 3, 64, 64) and torch.isfinite(out).all()
+    from mocov2_whisper_flamingo_amd._lib import AvsrHipError
+    with pytest.raises(AvsrHipError):                            # a frame's planes must fit in LDS
+        ops.video_color(torch.zeros(1, 1, 3, 128, 128, device=dev))
+
+
+@pytest.mark.gpu
 def test_logmel_rejects_bad_arguments(dev):
     from mocov2_whisper_flamingo_amd._lib import AvsrHipError
     tables = ops.logmel_tables(ops.MEL_WHISPER, dev)

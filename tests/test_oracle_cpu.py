@@ -213,3 +213,38 @@ def test_add_noise_reaches_the_requested_snr_and_spec_augment_bands():
     # 48 frames or fewer: the frame bands are skipped (:160-162), the mel-bin bands are not
     short = spec_augment(torch.ones(80, 48), [0, 0], [69, 0])
     assert int((short == 0).sum()) == 20 * 48 and (short[69:79] == 0).all() and (short[:10] == 0).all()
+
+
+def test_colour_transform_restatement_properties():
+    """The restated torchvision colour operations (PARITY UNPINNED: torchvision absent) have the properties their
+    definitions imply: identity at neutral factors, hue shifts compose modulo 1, contrast blends towards ONE grey
+    level per frame, saturation 0 and RandomGrayscale give equal channels, every result stays in [0, 1]; and the
+    host draws stay in ColorJitter(0.4, 0.4, 0.4, 0.1)'s ranges."""
+    import random
+    from oracle import ref_video as rv
+    from mocov2_whisper_flamingo_amd.transforms import color_draws
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(4, 3, 16, 16, generator=g)
+    assert (rv.adjust_brightness(x, 1.0) - x).abs().max() == 0
+    assert (rv.adjust_saturation(x, 1.0) - x).abs().max() == 0
+    assert (rv.adjust_contrast(x, 1.0) - x).abs().max() == 0
+    assert (rv.adjust_hue(x, 0.0) - x).abs().max() < 1e-5
+    assert (rv.adjust_hue(rv.adjust_hue(x, 0.3), -0.3) - x).abs().max() < 1e-4
+    flat = rv.adjust_contrast(x, 0.0)
+    for t in range(4):                                   # factor 0: every pixel = that frame's mean grey level
+        assert (flat[t] - rv.rgb_to_grayscale(x[t]).mean()).abs().max() < 1e-6
+    assert flat[0, 0, 0, 0] != flat[1, 0, 0, 0]
+    grey = rv.adjust_saturation(x, 0.0)
+    assert (grey[:, 0] - grey[:, 1]).abs().max() == 0 and (grey[:, 0] - grey[:, 2]).abs().max() == 0
+    out = rv.color_jitter(x, [3, 0, 2, 1], [1.4, 0.6, 1.4, 0.1])
+    assert out.min() >= 0 and out.max() <= 1
+    y = rv.video_transform_train(torch.rand(5, 3, 20, 24, generator=g) * 255, True, [1, 3, -1, 0], [0.7, 1.3, 1.0, -0.05],
+                                 True, [False, True, False, False, False], size=(8, 8))
+    assert y.shape == (5, 3, 8, 8)
+    mean, std = torch.tensor(rv.IMAGENET_MEAN), torch.tensor(rv.IMAGENET_STD)
+    assert (y[1] - (-mean / std).view(3, 1, 1)).abs().max() < 1e-6           # the zeroed frame, normalised
+    un = y[0] * std.view(3, 1, 1) + mean.view(3, 1, 1)                         # grayscale: equal channels before Normalize
+    assert (un[0] - un[1]).abs().max() < 1e-5
+    for seed in range(30):
+        order, f, grey_ = color_draws(random.Random(seed))
+        assert sorted(order) == [0, 1, 2, 3] and all(0.6 <= v <= 1.4 for v in f[:3]) and -0.1 <= f[3] <= 0.1
