@@ -152,6 +152,19 @@ int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, 
                   int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
                   float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
                   float p_drop, uint64_t seed, int causal);
+/* The same forward with a workspace that lets the bf16 MFMA kernel even out its last round of workgroups: when the
+ * number of (batch, head, 128-query tile) items leaves the chip's last round at most half full (Whisper-small at
+ * batch 8: 1152 items on 768 resident workgroups), the items of that round are computed by 2-4 workgroups each, every
+ * one over its share of the keys, and the last to finish sums the shares (same result up to fp32 summation order).
+ * workspace: 256-byte aligned, at least avsr_attn_fwd_workspace_bytes(...) bytes (0 = this shape is not split);
+ * its first ceil(4*items/256)*256 bytes are counters that must be ZERO before the first call and are left zero by
+ * every call, so one buffer zeroed once serves a whole stream of calls; calls that share a workspace must not
+ * overlap.  workspace == NULL or too small: exactly avsr_attn_fwd. */
+int64_t avsr_attn_fwd_workspace_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk, float p_drop, int causal);
+int avsr_attn_fwd_ws(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
+                     int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
+                     float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
+                     float p_drop, uint64_t seed, int causal, void* workspace, int64_t workspace_bytes);
 /* d_ws: fp32 [B,H,Tq] scratch (row sums of dO*O).  Not for a causal forward. */
 int avsr_attn_bwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
                   int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo, const void* dO, int64_t lddo,

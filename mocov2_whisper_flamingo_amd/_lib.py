@@ -61,6 +61,9 @@ SIGNATURES = {
                                       _vp, _i64]),
     "avsr_attn_fwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
                              _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64, _i32]),
+    "avsr_attn_fwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64, _f32, _i32]),
+    "avsr_attn_fwd_ws": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
+                                _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64, _i32, _vp, _i64]),
     "avsr_attn_bwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
                              _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64]),
     "avsr_gated_xattn_fwd_workspace_bytes": (_i64, [_c.POINTER(XattnBlock)]),

@@ -134,11 +134,6 @@ class AVNet(nn.Module):
             raise ops._lib.AvsrHipError("AVNet inputs must be on the GPU: this package has no CPU path")
         if graph:
             return self._encode_graph(inputBatch, ahead)
-        cdt = self.compute_dtype
-        # AUDIO: [B,3000,80] is already channels-last, the layout the conv kernel wants
-        channels_last = audioBatch.shape[2] == 80 and audioBatch.shape[1] % 3000 == 0
-        frames = audioBatch.shape[1] if channels_last else audioBatch.shape[2]
-        windows = frames // 3000 if (self.long_form and frames % 3000 == 0) else 1
         # The two frozen encoders are independent until the fusion: the visual frontend runs on a second HIP
         # stream so its many short kernels fill the CUs the audio encoder's GEMM tails leave idle (and vice versa).
         main = torch.cuda.current_stream()
@@ -147,29 +142,42 @@ class AVNet(nn.Module):
         if side is not None:
             side.wait_stream(main)                                          # the inputs are ready on `main`
             with torch.cuda.stream(side):
-                vis = self.visual_model(videoBatch, videoLen)               # [B,Tv,2048]
+                vis = self._run_visual(inputBatch)                          # [B,Tv,2048]
         if ahead:
             audio.wait_stream(main)
         with torch.cuda.stream(audio):
-            if windows > 1:                                                 # k x 30 s: k encoder windows per clip
-                if not channels_last:
-                    audioBatch, channels_last = ops.transpose2d(audioBatch, dtype=cdt), True
-                audioBatch = audioBatch.contiguous().view(audioBatch.shape[0] * windows, 3000, 80)
-            # only the first min(1500, T_video) encoder frames survive the truncation of models/av_net.py:91-96
-            n_video = videoBatch.shape[2] if (videoBatch.dim() == 6 and videoBatch.shape[1] == 1) else videoBatch.shape[1]
-            keep = n_video if (self.prune_unread_frames and windows == 1) else None
-            enc = self.whisper_model.encoder(audioBatch, attention_mask=None, dtype=cdt, channels_last=channels_last,
-                                             rows=keep)[0]
-            if windows > 1:
-                enc = enc.view(enc.shape[0] // windows, windows * enc.shape[1], enc.shape[2])
+            enc = self._run_audio(inputBatch)
         if side is None:
-            vis = self.visual_model(videoBatch, videoLen)                   # [B,Tv,2048]
+            vis = self._run_visual(inputBatch)
         done = []
         if side is not None:
             done.append((side, side.record_event()))
         if ahead:
             done.append((audio, audio.record_event()))
         return {"enc": enc, "vis": vis, "done": done, "inputs": inputBatch}
+
+    def _run_visual(self, inputBatch):
+        return self.visual_model(inputBatch[2], inputBatch[4])
+
+    def _run_audio(self, inputBatch):
+        audioBatch, videoBatch = inputBatch[0], inputBatch[2]
+        cdt = self.compute_dtype
+        # AUDIO: [B,3000,80] is already channels-last, the layout the conv kernel wants
+        channels_last = audioBatch.shape[2] == 80 and audioBatch.shape[1] % 3000 == 0
+        frames = audioBatch.shape[1] if channels_last else audioBatch.shape[2]
+        windows = frames // 3000 if (self.long_form and frames % 3000 == 0) else 1
+        if windows > 1:                                                 # k x 30 s: k encoder windows per clip
+            if not channels_last:
+                audioBatch, channels_last = ops.transpose2d(audioBatch, dtype=cdt), True
+            audioBatch = audioBatch.contiguous().view(audioBatch.shape[0] * windows, 3000, 80)
+        # only the first min(1500, T_video) encoder frames survive the truncation of models/av_net.py:91-96
+        n_video = videoBatch.shape[2] if (videoBatch.dim() == 6 and videoBatch.shape[1] == 1) else videoBatch.shape[1]
+        keep = n_video if (self.prune_unread_frames and windows == 1) else None
+        enc = self.whisper_model.encoder(audioBatch, attention_mask=None, dtype=cdt, channels_last=channels_last,
+                                         rows=keep)[0]
+        if windows > 1:
+            enc = enc.view(enc.shape[0] // windows, windows * enc.shape[1], enc.shape[2])
+        return enc
 
     def _capture_encoders(self, inputBatch, stream, main):
         """Static input buffers, one eager pass (weight packing, lazily set kernel attributes), then the capture."""

@@ -15,6 +15,7 @@
 //
 // Layout of every operand: element (b, t, h, d) at ptr + (b*T + t)*ld + h*64 + d.
 #include "common.h"
+#include <algorithm>
 
 #define HD 64
 #define LOG2E 1.4426950408889634f
@@ -82,20 +83,35 @@ template <bool DROP>
 #ifndef ATT_LAZY_LOG2
 #define ATT_LAZY_LOG2 8.0f
 #endif
+#ifndef ATT_NBUF
+#define ATT_NBUF 2
+#endif
 __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
                                                             long ldk, const bf16_t* __restrict__ V, long ldv,
                                                             bf16_t* __restrict__ O, long ldo, const uint8_t* __restrict__ mask,
                                                             float* __restrict__ lse, int Tq, int Tk, int H, float scale,
-                                                            float pdrop, uint64_t seed, int B, int causal) {
-    __shared__ __attribute__((aligned(16))) bf16_t Kbuf[2][64 * 64];      // double-buffered: one barrier per key tile
-    __shared__ __attribute__((aligned(16))) bf16_t Vbuf[2][64 * 64];
+                                                            float pdrop, uint64_t seed, int B, int causal,
+                                                            int whole_per_xcd, int nsplit, float* __restrict__ part_ws,
+                                                            int* __restrict__ tickets) {
+    __shared__ __attribute__((aligned(16))) bf16_t Kbuf[ATT_NBUF][64 * 64];      // ring: one barrier per key tile
+    __shared__ __attribute__((aligned(16))) bf16_t Vbuf[ATT_NBUF][64 * 64];
+    __shared__ int last_part;
     // 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs (id % 8), each with its own L2.  All
     // query tiles of one (batch, head) are given to ONE XCD so its K/V are fetched from the fabric once, not 8 times.
+    // An item is one (batch, head, 128-query tile).  The first whole_per_xcd items of an XCD are one workgroup each;
+    // each later item is nsplit workgroups, each over a contiguous share of the key tiles (the host picks the numbers
+    // so that the last round of workgroups fills the chip: 1.5 rounds of equal items otherwise take two).  The
+    // shares of an item leave their unnormalised sums in part_ws, and whichever finishes last adds them up.
     const int qtiles = (Tq + 127) >> 7, npairs = B * H;
-    const int per_xcd = (npairs + 7) >> 3;                         // grid = 8 * per_xcd * qtiles workgroups
+    const int per_xcd = (npairs + 7) >> 3;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int pair = xcd * per_xcd + slot / qtiles, qt = slot - (slot / qtiles) * qtiles;
-    if (pair >= npairs || slot >= per_xcd * qtiles) return;
+    int item = slot, part = 0, nparts = 1;
+    if (slot >= whole_per_xcd) {
+        const int e = slot - whole_per_xcd;
+        item = whole_per_xcd + e / nsplit; part = e - (e / nsplit) * nsplit; nparts = nsplit;
+    }
+    const int pair = xcd * per_xcd + item / qtiles, qt = item - (item / qtiles) * qtiles;
+    if (pair >= npairs || item >= per_xcd * qtiles) return;
     const int b = pair / H, h = pair - b * H;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r = lane & 31, hf = lane >> 5;
@@ -114,7 +130,6 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
     float mrun = -INFINITY, lsum = 0.f;                       // running max (raw score units), partial row sum
     const float sc2 = scale * LOG2E;
     const float lazy = ATT_LAZY_LOG2 / sc2;                   // in raw score units
-    const int lc = t & 7, lr = t >> 3;                        // staging: chunk, row (+32)
     const bf16_t* Kb = K + (long)b * Tk * ldk + h * HD;
     const bf16_t* Vb = V + (long)b * Tk * ldv + h * HD;
     const uint8_t* mb = mask ? mask + (long)b * Tk : nullptr;
@@ -122,37 +137,64 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
     const int tk4 = (Tk + 3) >> 2;
     const uint64_t row = ((uint64_t)b * H + h) * Tq + q;
 
-    // register prefetch of the next K/V tile: issued before the current tile's math, written to LDS
-    // after it, so the global-load latency hides under the MFMA / softmax work
-    bf16x8 kreg[2], vreg[2];
-    auto prefetch = [&](int kv0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = kv0 + lr + 32 * i;
-            const bool ok = key < Tk;
-            kreg[i] = ok ? *(const bf16x8*)(Kb + (long)key * ldk + lc * 8) : zero8;
-            vreg[i] = ok ? *(const bf16x8*)(Vb + (long)key * ldv + lc * 8) : zero8;
-        }
+    // K / V tiles go global -> LDS directly (LDS-DMA): a wave instruction moves 8 key rows x 128 B into 1 KiB of
+    // lane-linear LDS, so the XOR swizzle of k_off / v_off is applied to the chunk each lane FETCHES.  Each wave
+    // moves pieces 2*wave and 2*wave+1 of both tiles: four instructions per 64-key tile, no staging registers, no
+    // ds_write.  The per-lane byte offsets are constants of the kernel (the tile base advances in scalar registers);
+    // only a tile that reaches past Tk recomputes them with its rows clamped onto the last key (those keys are
+    // masked to -inf further down, and a clamped V row is finite, so 0 * V stays 0).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int prow = lane >> 3, pch = lane & 7;
+    auto piece_off = [&](int i, int kv0, unsigned& ko, unsigned& vo) {
+        const int rr = (2 * wave_u + i) * 8 + prow;
+        const int kc = pch ^ ((rr >> 1) & 7), vc = pch ^ (((rr >> 1) & 1) << 2);
+        const long key = min(rr, Tk - 1 - kv0);
+        ko = (unsigned)((key * ldk + kc * 8) * (long)sizeof(bf16_t));
+        vo = (unsigned)((key * ldv + vc * 8) * (long)sizeof(bf16_t));
     };
-    auto stage = [&](int buf) {
+    unsigned koff[2], voff[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *(bf16x8*)&Kbuf[buf][k_off(lr + 32 * i, lc)] = kreg[i];
-            *(bf16x8*)&Vbuf[buf][v_off(lr + 32 * i, lc)] = vreg[i];
+    for (int i = 0; i < 2; ++i) piece_off(i, 0, koff[i], voff[i]);
+    auto dma_tile = [&](int kv0, int buf) {
+        const char* kb = (const char*)(Kb + (long)kv0 * ldk);
+        const char* vb = (const char*)(Vb + (long)kv0 * ldv);
+        if (kv0 + 64 <= Tk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                dma_piece(kb, koff[i], (const char*)&Kbuf[buf][(2 * wave_u + i) * 512]);
+                dma_piece(vb, voff[i], (const char*)&Vbuf[buf][(2 * wave_u + i) * 512]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                unsigned ko, vo;
+                piece_off(i, kv0, ko, vo);
+                dma_piece(kb, ko, (const char*)&Kbuf[buf][(2 * wave_u + i) * 512]);
+                dma_piece(vb, vo, (const char*)&Vbuf[buf][(2 * wave_u + i) * 512]);
+            }
         }
     };
     // causal: query i sees keys <= i + (Tk - Tq) (the last Tq positions of a Tk-long sequence), so this
     // workgroup's key loop ends at the diagonal of its last query row
     const int coff = Tk - Tq;
-    const int kend = causal ? min(Tk, qt * 128 + 128 + coff) : Tk;
-    prefetch(0);
-    stage(0);
+    int kbeg = 0, kend = causal ? min(Tk, qt * 128 + 128 + coff) : Tk;
+    if (nparts > 1) {                                         // this workgroup's share of the key tiles
+        const int nt = (kend + 63) >> 6;
+        kbeg = 64 * (part * nt / nparts);
+        kend = min(kend, 64 * ((part + 1) * nt / nparts));
+    }
+    dma_tile(kbeg, 0);
+    if (ATT_NBUF == 3 && kbeg + 64 < kend) { dma_tile(kbeg + 64, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kv0 = 0, cur = 0; kv0 < kend; kv0 += 64, cur ^= 1) {
+    for (int kv0 = kbeg, cur = 0; kv0 < kend; kv0 += 64, cur = (cur + 1 == ATT_NBUF ? 0 : cur + 1)) {
         const bf16_t* Ks = Kbuf[cur];
         const bf16_t* Vs = Vbuf[cur];
-        const bool more = kv0 + 64 < kend;
-        if (more) prefetch(kv0 + 64);                         // lands in registers while this tile is computed
+        // a later tile lands in the buffer that was last read one barrier ago while this one is computed: with
+        // three buffers the tile after next, so a load has two tiles of arithmetic to arrive in
+        const int ahead = 64 * (ATT_NBUF - 1);
+        const bool issue = kv0 + ahead < kend;
+        if (issue) dma_tile(kv0 + ahead, cur == 0 ? ATT_NBUF - 1 : cur - 1);
 
         // 32 keys at a time (rolled): half the score registers and a quarter of the K / V fragments are live at
         // once, which is what lets four waves share a SIMD (the 64-key form needed ~250 VGPRs: two waves).
@@ -249,8 +291,52 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr_frag(Vs, st, s2, db, lane), pf, oacc[db], 0, 0, 0);
             }
         }
-        if (more) stage(cur ^ 1);                             // the other buffer was last read one barrier ago
+        // this wave's pieces of the NEXT tile are in LDS (the four of the tile after it may still be in flight)
+        if (ATT_NBUF == 3 && issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+    if (nparts > 1) {
+        // A wave's partial result is its 32 accumulator registers, its reference maximum and its partial row sum, one
+        // 256-byte row of the workspace per register.  The shares are written THROUGH the caches (system-scope
+        // stores) and read back past them (system-scope loads), so publishing them takes no write-back or
+        // invalidation of the XCD's whole L2, which a device-scope fence per workgroup would (measured: 2.4x the
+        // kernel time).  Order: stores acknowledged (vmcnt 0) -> workgroup barrier -> one ticket per workgroup; the
+        // workgroup that draws the last ticket of its item sums all shares and carries on to the epilogue.
+        const int sidx = xcd * (per_xcd * qtiles - whole_per_xcd) + (item - whole_per_xcd);
+        float* wp = part_ws + (((long)sidx * nparts + part) * 4 + wave) * (34 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __hip_atomic_store(&wp[i * 64], oacc[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&wp[(16 + i) * 64], oacc[1][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __hip_atomic_store(&wp[32 * 64], mrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&wp[33 * 64], lsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) last_part = __hip_atomic_fetch_add(&tickets[sidx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nparts - 1;
+        __syncthreads();
+        if (!last_part) return;
+        const float* rp = part_ws + (((long)sidx * nparts) * 4 + wave) * (34 * 64) + lane;
+        float mall = -INFINITY;
+        for (int p = 0; p < nparts; ++p)
+            mall = fmaxf(mall, __hip_atomic_load(&rp[(long)p * 4 * 34 * 64 + 32 * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+        lsum = 0.f;
+        for (int p = 0; p < nparts; ++p) {
+            const float* pp = rp + (long)p * 4 * 34 * 64;
+            const float mp = __hip_atomic_load(&pp[32 * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const float a = mp == -INFINITY ? 0.f : exp2f((mp - mall) * sc2);
+            lsum = fmaf(a, __hip_atomic_load(&pp[33 * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), lsum);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                oacc[0][i] = fmaf(a, __hip_atomic_load(&pp[i * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), oacc[0][i]);
+                oacc[1][i] = fmaf(a, __hip_atomic_load(&pp[(16 + i) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), oacc[1][i]);
+            }
+        }
+        mrun = mall;
+        if (t == 0) tickets[sidx] = 0;                        // the next launch on this workspace starts from zero
     }
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
@@ -885,10 +971,48 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_valu_kernel(const T* __restr
 }
 
 // ---------------------------------------------------------------- host ----
-extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
-                             int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
-                             float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
-                             float p_drop, uint64_t seed, int causal) {
+// How the forward grid is cut (see the kernel): per XCD, `whole` items run as one workgroup and the remaining `rest`
+// as `nsplit` workgroups each.  Splitting pays when the last round of equal workgroups would leave at least half of
+// the chip's resident-workgroup slots empty; it needs the caller's workspace, no causal mask, and at least four key
+// tiles per share.
+struct AttnSplit { int whole, rest, nsplit; };
+static AttnSplit attn_split_plan(int64_t B, int64_t H, int64_t Tq, int64_t Tk, int causal, bool dropout) {
+    const int per_xcd = (int)((B * H + 7) / 8), qtiles = (int)((Tq + 127) / 128), items = per_xcd * qtiles;
+    AttnSplit pl{items, 0, 1};
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = n;
+        if (cus <= 0) cus = 256;
+    }
+    static int occ[2] = {0, 0};                               // resident workgroups per CU, as the runtime computes it
+    if (!occ[dropout]) {
+        int n = 0;
+        const hipError_t e = dropout ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<true>, 256, 0)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<false>, 256, 0);
+        occ[dropout] = (e == hipSuccess && n > 0) ? n : ATT_OCC;
+    }
+    const int slots = (cus / 8) * occ[dropout];               // resident workgroups per XCD
+    const int rem = items % slots;
+    if (causal || rem == 0 || slots <= 0) return pl;
+    const int ns = std::min<int>(std::min<int>(4, slots / rem), (int)((Tk + 63) / 64 / 4));
+    if (ns < 2) return pl;
+    pl.whole = items - rem; pl.rest = rem; pl.nsplit = ns;
+    return pl;
+}
+
+extern "C" int64_t avsr_attn_fwd_workspace_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk, float p_drop, int causal) {
+    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return 0;
+    const AttnSplit pl = attn_split_plan(B, H, Tq, Tk, causal, p_drop > 0.f);
+    if (pl.nsplit < 2) return 0;
+    const int64_t nitems = 8LL * pl.rest;
+    return ((nitems * 4 + 255) / 256) * 256 + nitems * pl.nsplit * 4 * 34 * 64 * 4;
+}
+
+extern "C" int avsr_attn_fwd_ws(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
+                                int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
+                                float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
+                                float p_drop, uint64_t seed, int causal, void* workspace, int64_t workspace_bytes) {
     if (!Q || !K || !V || !O || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return AVSR_EINVAL;
     if (causal && Tk < Tq) return AVSR_EINVAL;
     if (use_mfma < 0 || use_mfma > 2) return AVSR_EINVAL;
@@ -900,8 +1024,11 @@ extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, cons
         if (p_drop < 0.f || p_drop >= 1.f) return AVSR_EINVAL;
         if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return AVSR_EUNSUPPORTED;
         if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) % 16 || (uintptr_t)O % 8) return AVSR_EUNSUPPORTED;
-        if (B * H * ((Tq + 127) / 128) > 0x3fffffff) return AVSR_EUNSUPPORTED;
-        dim3 grid((unsigned)(8 * ((B * H + 7) / 8) * ((Tq + 127) / 128)));
+        if (B * H * ((Tq + 127) / 128) > 0x0fffffff) return AVSR_EUNSUPPORTED;
+        // the K / V tiles are addressed by 32-bit byte offsets from the tile's first key
+        if (64 * std::max(ldk, ldv) * 2 > 0x7fffffffLL) return AVSR_EUNSUPPORTED;
+        const int per_xcd = (int)((B * H + 7) / 8), qtiles = (int)((Tq + 127) / 128);
+        dim3 grid((unsigned)(8 * per_xcd * qtiles));
         if (use_mfma == 2) {                                  // fp8 products; no dropout form
             if (p_drop != 0.f) return AVSR_EUNSUPPORTED;
             hipLaunchKernelGGL(attn_fwd_fp8_kernel, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq, (const bf16_t*)K,
@@ -909,14 +1036,27 @@ extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, cons
                                (int)H, scale, (int)B, causal);
             return avsr_launch_status();
         }
+        AttnSplit pl = attn_split_plan(B, H, Tq, Tk, causal, p_drop > 0.f);
+        float* part_ws = nullptr;
+        int* tickets = nullptr;
+        if (pl.nsplit >= 2 && workspace && ((uintptr_t)workspace % 256) == 0 &&
+            workspace_bytes >= avsr_attn_fwd_workspace_bytes(B, H, Tq, Tk, p_drop, causal)) {
+            tickets = (int*)workspace;
+            part_ws = (float*)((char*)workspace + ((8LL * pl.rest * 4 + 255) / 256) * 256);
+            grid = dim3((unsigned)(8 * (pl.whole + pl.rest * pl.nsplit)));
+        } else {
+            pl = AttnSplit{per_xcd * qtiles, 0, 1};
+        }
         if (p_drop > 0.f)
             hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                                (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
-                               (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, (int)B, causal);
+                               (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, (int)B, causal, pl.whole, pl.nsplit, part_ws,
+                               tickets);
         else
             hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                                (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
-                               (int)Tq, (int)Tk, (int)H, scale, 0.f, seed, (int)B, causal);
+                               (int)Tq, (int)Tk, (int)H, scale, 0.f, seed, (int)B, causal, pl.whole, pl.nsplit, part_ws,
+                               tickets);
         return avsr_launch_status();
     }
     dim3 grid((unsigned)((Tq + 31) / 32), (unsigned)H, (unsigned)B);
@@ -930,6 +1070,14 @@ extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, cons
                            (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, causal);
     else return AVSR_EINVAL;
     return avsr_launch_status();
+}
+
+extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
+                             int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
+                             float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
+                             float p_drop, uint64_t seed, int causal) {
+    return avsr_attn_fwd_ws(stream, dtype, use_mfma, Q, ldq, K, ldk, V, ldv, O, ldo, key_mask, lse, B, H, Tq, Tk, head_dim,
+                            scale, p_drop, seed, causal, nullptr, 0);
 }
 
 extern "C" int avsr_attn_bwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K, int64_t ldk,

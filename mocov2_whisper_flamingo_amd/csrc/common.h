@@ -183,3 +183,19 @@ __host__ __device__ __forceinline__ bool avsr_attn_keep(uint64_t seed, uint64_t 
     avsr_philox4(seed, avsr_attn_counter(row, tk4, key), o);
     return avsr_bits_keep(o[key & 3], p);
 }
+
+// ------------------------------------------------------------ LDS-DMA ----
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One LDS-DMA piece from a UNIFORM base (scalar register pair) plus a 32-bit per-lane byte offset: the
+// saddr form of the instruction, which the builtin does not select (it re-associates the sum into a 64-bit
+// per-lane pointer and pays a 64-bit vector add per piece and K-step).  M0 carries the LDS destination and is
+// compiler-reserved: saved and restored inside the statement.  The compiler does not count this load: every
+// user waits with an explicit s_waitcnt vmcnt before the barrier that publishes the stage.
+__device__ __forceinline__ void dma_piece(const char* sbase, unsigned voff, const char* lds_dst) {
+    unsigned keep;
+    const unsigned ldsa = (unsigned)(uintptr_t)(lptr_t)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(ldsa) : "memory");
+}

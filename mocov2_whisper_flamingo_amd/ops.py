@@ -4,6 +4,7 @@ and launches on torch's current stream.  torch only provides device memory and
 the stream.
 """
 import ctypes
+import os
 import torch
 
 from . import _lib
@@ -195,10 +196,31 @@ def _bthd(t, H):
     return t.stride(1)
 
 
-def attn_fwd(q, k, v, H, *, key_mask=None, scale=1.0, use_mfma=False, save_lse=False, p_drop=0.0, seed=0, causal=False):
+# AVSR_ATTN_SPLIT=0 keeps attn_fwd on the one-workgroup-per-item grid even when a workspace is given (A/B switch).
+ATTN_SPLIT = os.environ.get("AVSR_ATTN_SPLIT", "1") != "0"
+
+
+class AttnWorkspace:
+    """Scratch for attn_fwd's split last round (avsr_attn_fwd_ws): a byte buffer zeroed when it is allocated - the
+    kernel leaves its counters zero - and reused by every call of one stream of calls (e.g. the layers of an encoder).
+    Calls that share one must not overlap on the device."""
+
+    def __init__(self):
+        self._buf = None
+
+    def get(self, nbytes, device):
+        if self._buf is None or self._buf.numel() < nbytes or self._buf.device != device:
+            self._buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        return self._buf
+
+
+def attn_fwd(q, k, v, H, *, key_mask=None, scale=1.0, use_mfma=False, save_lse=False, p_drop=0.0, seed=0, causal=False,
+             workspace=None):
     """q: [B,Tq,H*64] view, k/v: [B,Tk,H*64] views (may be column slices of a fused QKV buffer).
     ``causal``: query i sees keys <= i + (Tk - Tq); forward only (attn_bwd has no causal form).
-    ``use_mfma``: False = fp32-math kernel, True = bf16 MFMA, "fp8" = e4m3 MFMA products (forward only)."""
+    ``use_mfma``: False = fp32-math kernel, True = bf16 MFMA, "fp8" = e4m3 MFMA products (forward only).
+    ``workspace``: an AttnWorkspace lets the bf16 MFMA kernel split the items of a half-empty last round of
+    workgroups over the keys (same result up to fp32 summation order)."""
     use_mfma = 2 if use_mfma == "fp8" else int(bool(use_mfma))
     lib = _lib.load()
     _need_cuda(q, k, v, key_mask)
@@ -207,9 +229,14 @@ def attn_fwd(q, k, v, H, *, key_mask=None, scale=1.0, use_mfma=False, save_lse=F
     lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device) if save_lse else None
     if key_mask is not None and (key_mask.dtype != torch.uint8 or not key_mask.is_contiguous()):
         raise ValueError("key_mask must be contiguous uint8 [B,Tk]")
-    check(lib.avsr_attn_fwd(_stream(), _dt(q), int(use_mfma), q.data_ptr(), _bthd(q, H), k.data_ptr(), _bthd(k, H),
-                            v.data_ptr(), _bthd(v, H), o.data_ptr(), H * 64, _p(key_mask), _p(lse), B, H, Tq, Tk, 64,
-                            scale, p_drop, seed, int(causal)), "avsr_attn_fwd")
+    ws, ws_bytes = None, 0
+    if workspace is not None and use_mfma == 1 and ATTN_SPLIT:
+        ws_bytes = int(lib.avsr_attn_fwd_workspace_bytes(B, H, Tq, Tk, p_drop, int(causal)))
+        if ws_bytes:
+            ws = workspace.get(ws_bytes, q.device)
+    check(lib.avsr_attn_fwd_ws(_stream(), _dt(q), int(use_mfma), q.data_ptr(), _bthd(q, H), k.data_ptr(), _bthd(k, H),
+                               v.data_ptr(), _bthd(v, H), o.data_ptr(), H * 64, _p(key_mask), _p(lse), B, H, Tq, Tk, 64,
+                               scale, p_drop, seed, int(causal), _p(ws), ws.numel() if ws is not None else 0), "avsr_attn_fwd_ws")
     return (o, lse) if save_lse else o
 
 

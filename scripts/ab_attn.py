@@ -11,7 +11,7 @@ for f in sorted(glob.glob('scripts/variants/libavsr_*.so')):
     l.avsr_attn_fwd.restype, l.avsr_attn_fwd.argtypes = res, args
     libs[os.path.basename(f)[9:-3]] = l
 stream = torch.cuda.current_stream().cuda_stream
-for B, H, T in [(8, 12, 1500), (8, 20, 1500), (8, 6, 1500)]:
+for B, H, T in [(8, 12, 1500), (8, 8, 1500), (16, 16, 1500)]:
     D = H * 64
     qkv = torch.randn(B, T, 3 * D, device=dev).to(torch.bfloat16)
     o = torch.empty(B, T, D, device=dev, dtype=torch.bfloat16)

@@ -219,6 +219,44 @@ def test_attn_mfma_fwd(dev, Tq, Tk):
         assert rel_err(lse, torch.logsumexp(s, -1)) < 1e-2
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,masked,p", [
+    (8, 12, 1500, 1500, False, 0.0),     # Whisper-small at batch 8: 144 items per XCD = one full round + half a round
+    (5, 8, 2560, 1100, True, 0.0),       # 100 items per XCD: the last 4 are cut four ways; masked keys in one share
+    (4, 6, 500, 500, False, 0.0),        # fewer items than resident workgroups: every item cut in two
+    (4, 6, 500, 520, True, 0.25),        # the dropout form; the mask is a function of the absolute key index
+])
+def test_attn_fwd_split_last_round(dev, B, H, Tq, Tk, masked, p):
+    """With a workspace the forward hands the items of a half-empty last round of workgroups to several workgroups
+    each (shares of the keys, summed by the last to finish).  Same numbers as the one-workgroup form up to the fp32
+    summation order, twice in a row on one workspace (the counters must come back to zero)."""
+    lib = ops._lib.load()
+    assert lib.avsr_attn_fwd_workspace_bytes(B, H, Tq, Tk, p, 0) > 0, "shape chosen to be split"
+    assert lib.avsr_attn_fwd_workspace_bytes(B, H, Tq, Tk, p, 1) == 0, "never with a causal mask"
+    g = torch.Generator().manual_seed(B * Tq)
+    q = rnd(g, B, Tq, H * 64).to(dev, torch.bfloat16)
+    kv = rnd(g, B, Tk, 2 * H * 64).to(dev, torch.bfloat16)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, Tk, dtype=torch.uint8)
+        mask[0, Tk // 3:] = 1                   # a whole share of the keys is masked for clip 0
+        mask[1, :] = 1                          # and clip 1 has no key at all: zeros, lse = +inf
+        mask = mask.to(dev)
+    kw = dict(key_mask=mask, scale=0.125, use_mfma=True, save_lse=True, p_drop=p, seed=77)
+    o0, l0 = ops.attn_fwd(q, kv[:, :, :H * 64], kv[:, :, H * 64:], H, **kw)
+    ws = ops.AttnWorkspace()
+    for _ in range(2):
+        o1, l1 = ops.attn_fwd(q, kv[:, :, :H * 64], kv[:, :, H * 64:], H, workspace=ws, **kw)
+        assert ws._buf is not None
+        assert torch.isfinite(o1.float()).all()
+        assert (o1.float() - o0.float()).abs().max() <= 2 ** -7 * o0.float().abs().max()      # a bf16 ulp or two
+        assert rel_err(o1, o0) < 1e-2      # the shares round P to bf16 against their own reference maxima
+        fin = torch.isfinite(l0)
+        assert torch.equal(fin, torch.isfinite(l1))
+        assert (l1[fin] - l0[fin]).abs().max() < 1e-4
+    if masked:
+        assert o1[1].abs().max() == 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("p", [0.0, 0.25])
 def test_attn_valu_fwd_bwd(dev, dtype, p):
