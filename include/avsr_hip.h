@@ -373,6 +373,12 @@ int avsr_cast_rows(avsr_stream_t stream, int in_dtype, int out_dtype, const void
 int avsr_transpose(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, int64_t ldx, int64_t sx,
                    void* y, int64_t ldy, int64_t sy, int64_t batch, int64_t R, int64_t C, float scale,
                    void* copy, int64_t ldc);
+/* Weight and bias gradient of an nn.Linear in one pass (autograd of F.linear as models/utils.py:42 and
+ * models/gate_cross_attention.py:16,23-26 call it): C[N,K] (+)= A^T B and colsum[n] (+)= sum_m A[m][n], with
+ * A = dY [M,N] and B = X [M,K] bf16, row-major as the forward and backward passes leave them (no transposed
+ * copies); C, colsum fp32.  lda, ldb multiples of 8 elements, A and B 16-byte aligned; colsum may be NULL. */
+int avsr_gemm_tn(avsr_stream_t stream, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                 int64_t M, int64_t N, int64_t K, int accumulate, float* colsum, int accumulate_colsum);
 /* out[n] (+)= sum_m x[m][n]  (bias gradients) */
 int avsr_colsum(avsr_stream_t stream, int dtype, const void* x, int64_t ld, int64_t M, int64_t N, float* out,
                 int accumulate);

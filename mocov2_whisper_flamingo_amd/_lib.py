@@ -55,6 +55,7 @@ class XattnGrads(_c.Structure):
 SIGNATURES = {
     "avsr_version": (_c.c_char_p, []),
     "avsr_gemm_nt": (_i32, [_vp, _c.POINTER(GemmDesc)]),
+    "avsr_gemm_tn": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i32]),
     "avsr_layernorm_fwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _f32]),
     "avsr_layernorm_bwd": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64]),
     "avsr_layernorm_bwd_res": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64,

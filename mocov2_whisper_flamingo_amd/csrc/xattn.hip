@@ -95,6 +95,9 @@ struct G {
 // scratch ([N,Mp] and [K,Mp], Mp = M rounded up to 8, padding zeroed) so the product is the NT form again.
 int param_grads(avsr_stream_t s, int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t M, int64_t N,
                 int64_t K, float* dw, int64_t lddw, float* db, char* tA, char* tB) {
+    // bf16: one pass over dY and X as they lie in memory (contraction over their rows, bias gradient included)
+    if (dtype == AVSR_BF16 && lddy % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)dy | (uintptr_t)x) % 16 == 0)
+        return avsr_gemm_tn(s, dy, lddy, x, ldx, dw, lddw, M, N, K, 1, db, 1);
     const size_t es = dtype == AVSR_BF16 ? 2 : 4;
     const int64_t Mp = (M + 7) / 8 * 8;
     if (Mp != M) {

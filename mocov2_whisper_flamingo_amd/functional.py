@@ -114,6 +114,22 @@ def _param_grads(dy, x, has_bias, sink):
 
 
 def _param_grads_here(dy, x, has_bias, pw, pb, rows, parts):
+    if ops.gemm_tn_ok(dy, x):                               # bf16: one pass over dY and X as they lie in memory
+        gw = grad_sink(pw, rows)
+        gb = grad_sink(pb, rows) if has_bias else None
+        db = None
+        if has_bias and gb is None:
+            db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device)
+        if gw is not None:
+            ops.gemm_tn(dy, x, out=gw, accumulate=True, colsum=gb if gb is not None else db,
+                        accumulate_colsum=gb is not None)
+            dw = None
+            grad_done(pw, parts)
+        else:
+            dw = ops.gemm_tn(dy, x, colsum=gb if gb is not None else db, accumulate_colsum=gb is not None)
+        if gb is not None:
+            grad_done(pb, parts)
+        return dw, db
     dyt = ops.transpose2d(dy, pad_to=8)                     # [N, Mp]
     xt = ops.transpose2d(x, pad_to=8)                       # [K, Mp]
     gw = grad_sink(pw, rows)

@@ -555,6 +555,33 @@ def transpose2d(x, dtype=None, scale=1.0, pad_to=1, with_copy=False):
     return (y, cp) if with_copy else y
 
 
+def gemm_tn_ok(a, b):
+    """True when gemm_tn takes these operands as they are (bf16, unit inner stride, 16-byte rows)."""
+    return (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
+            and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
+def gemm_tn(a, b, out=None, accumulate=False, colsum=None, accumulate_colsum=False):
+    """out[N,K] (+)= a^T b for row-major bf16 a [M,N], b [M,K] (fp32 result), and colsum[n] (+)= sum_m a[m][n]:
+    the weight and bias gradients of a linear layer from dY and X as they lie in memory."""
+    lib = _lib.load()
+    _need_cuda(a, b, out, colsum)
+    (M, N), K = a.shape, b.shape[1]
+    if b.shape[0] != M:
+        raise ValueError("gemm_tn: operands must have the same number of rows")
+    if out is None:
+        out = torch.empty((N, K), dtype=torch.float32, device=a.device)
+        accumulate = False
+    if out.dtype != torch.float32 or out.stride(1) != 1 or tuple(out.shape) != (N, K):
+        raise ValueError("gemm_tn: out must be fp32 [N,K] with unit inner stride")
+    if colsum is not None and (colsum.dtype != torch.float32 or not colsum.is_contiguous() or colsum.numel() != N):
+        raise ValueError("gemm_tn: colsum must be contiguous fp32 [N]")
+    check(lib.avsr_gemm_tn(_stream(), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
+                           M, N, K, int(accumulate), _p(colsum), int(accumulate_colsum)), "avsr_gemm_tn")
+    return out
+
+
 def colsum(x, out=None, accumulate=False):
     lib = _lib.load()
     M, N = x.shape

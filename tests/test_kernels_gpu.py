@@ -219,6 +219,35 @@ def test_attn_mfma_fwd(dev, Tq, Tk):
         assert rel_err(lse, torch.logsumexp(s, -1)) < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(600, 512, 512), (600, 2048, 512), (600, 51865, 512), (75, 100, 72), (1, 64, 64),
+                                   (1000, 520, 2048)])
+def test_gemm_tn_weight_gradient(dev, M, N, K):
+    """dW = dY^T X and db = column sums of dY from the row-major operands (no transposed copies), written or
+    accumulated; ragged M / N / K and a padded row pitch (N = 51865 in rows of 51872)."""
+    g = torch.Generator().manual_seed(M + N)
+    ldn, ldk = (N + 7) // 8 * 8, (K + 7) // 8 * 8
+    dy = torch.full((M, ldn), 7.0)                 # padding columns hold junk: they must not reach the results
+    x = torch.full((M, ldk), -3.0)
+    dy[:, :N] = rnd(g, M, N, dtype=torch.bfloat16)
+    x[:, :K] = rnd(g, M, K, dtype=torch.bfloat16)
+    dyd, xd = dy.to(dev, torch.bfloat16)[:, :N], x.to(dev, torch.bfloat16)[:, :K]
+    assert ops.gemm_tn_ok(dyd, xd)
+    ref_w = dy[:, :N].double().t() @ x[:, :K].double()
+    ref_b = dy[:, :N].double().sum(0)
+    cs = torch.empty(N, device=dev)
+    w = ops.gemm_tn(dyd, xd, colsum=cs)
+    assert rel_err(w, ref_w) < 1e-5 and rel_err(cs, ref_b) < 1e-5
+    w0 = rnd(g, N, K).to(dev)
+    b0 = rnd(g, N).to(dev)
+    w1, b1 = w0.clone(), b0.clone()
+    ops.gemm_tn(dyd, xd, out=w1, accumulate=True, colsum=b1, accumulate_colsum=True)
+    assert rel_err(w1, w0.cpu().double() + ref_w) < 1e-5 and rel_err(b1, b0.cpu().double() + ref_b) < 1e-5
+    ld = K + 3                                      # a row slice of a wider fp32 buffer (the flat gradient buffer)
+    wide = torch.zeros(N, ld, device=dev)
+    ops.gemm_tn(dyd, xd, out=wide[:, :K])
+    assert rel_err(wide[:, :K], ref_w) < 1e-5 and wide[:, K:].abs().max() == 0
+
+
 @pytest.mark.parametrize("B,H,Tq,Tk,masked,p", [
     (8, 12, 1500, 1500, False, 0.0),     # Whisper-small at batch 8: 144 items per XCD = one full round + half a round
     (5, 8, 2560, 1100, True, 0.0),       # 100 items per XCD: the last 4 are cut four ways; masked keys in one share
