@@ -16,6 +16,7 @@
 // Layout of every operand: element (b, t, h, d) at ptr + (b*T + t)*ld + h*64 + d.
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 #define HD 64
 #define LOG2E 1.4426950408889634f
@@ -67,7 +68,7 @@ __device__ __forceinline__ uint64_t dead_keys(const uint8_t* mb, int kv0, int Tk
     return __ballot(key >= Tk || (mb && mb[key < Tk ? key : 0]));
 }
 
-template <bool DROP>
+template <bool DROP, bool PIPE>
 #ifndef ATT_OCC
 #define ATT_OCC 3
 #endif
@@ -83,8 +84,11 @@ template <bool DROP>
 #ifndef ATT_LAZY_LOG2
 #define ATT_LAZY_LOG2 8.0f
 #endif
+#ifndef ATT_PIPE
+#define ATT_PIPE 1
+#endif
 #ifndef ATT_NBUF
-#define ATT_NBUF 2
+#define ATT_NBUF 3
 #endif
 __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
                                                             long ldk, const bf16_t* __restrict__ V, long ldv,
@@ -187,7 +191,107 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
     if (ATT_NBUF == 3 && kbeg + 64 < kend) { dma_tile(kbeg + 64, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kv0 = kbeg, cur = 0; kv0 < kend; kv0 += 64, cur = (cur + 1 == ATT_NBUF ? 0 : cur + 1)) {
+    int kv0 = kbeg, cur = 0;
+    // PIPE (no key mask, no causal mask, no dropout: the Whisper encoder): the two matrix products of neighbouring
+    // 32-key sub-tiles are software-pipelined inside the wave.  While the softmax of sub-tile j runs on the vector
+    // ALU, the matrix pipe works on S(j+1) = K.Q^T, issued just before it, and then on the P.V of j: one
+    // instruction stream with an MFMA every few vector instructions (the order is pinned chunk by chunk), instead of
+    // a product, then its softmax, then the next product, each waiting for the one before.  Costs a second score
+    // accumulator (16 registers) and a third K/V buffer: the next tile must be resident before this one is finished.
+    if constexpr (PIPE) {
+        static_assert(!PIPE || (ATT_NBUF == 3 && !DROP), "the pipelined loop needs the three-buffer ring");
+        const int L = (kend - kbeg + 63) >> 6;               // tiles; only the last can reach past Tk
+        float ps0 = 0.f, ps1 = 0.f;
+        auto pipe_step = [&](f32x16& sc, f32x16& sn, const bf16_t* Kn, int hn, const bf16_t* Vc, int hc, int tile0) {
+            constexpr bool NEXT = true;       // past the last tile the scores of a stale buffer are computed and dropped
+            // loads first: the K fragments of the next sub-tile and the first two V fragments of this one land
+            // while the row maximum is found
+            bf16x8 kf[4];
+            if constexpr (NEXT) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8*)&Kn[k_off(32 * hn + r, 2 * ks + hf)];
+            }
+            bf16x8 vf0 = read_tr_frag(Vc, hc, 0, 0, lane), vf1 = read_tr_frag(Vc, hc, 0, 1, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tile0 + 64 > Tk) {                            // block-uniform: the tile that reaches past Tk
+                const uint32_t dead = (uint32_t)(dead_keys(nullptr, tile0, Tk, lane) >> (32 * hc));
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if ((dead >> ((i & 3) + 8 * (i >> 2) + 4 * hf)) & 1) sc[i] = -INFINITY;
+            }
+            float mx = vmax3(sc[0], sc[1], sc[2]);
+            float my = vmax3(sc[3], sc[4], sc[5]);
+            mx = vmax3(mx, sc[6], sc[7]);
+            my = vmax3(my, sc[8], sc[9]);
+            mx = vmax3(mx, sc[10], sc[11]);
+            my = vmax3(my, sc[12], sc[13]);
+            mx = vmax3(mx, sc[14], sc[15]);
+            mx = vmax3(mx, my, my);
+            mx = max_across_halves(mx);
+            if (__any(mx > mrun + lazy)) {
+                const float mnew = fmaxf(mrun, mx);
+                const float alpha = mnew > mrun ? exp2f((mrun - mnew) * sc2) : 1.0f;
+                mrun = mnew;
+                lsum *= alpha; ps0 *= alpha; ps1 *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+            }
+            const float msc = mrun == -INFINITY ? 0.f : mrun * sc2;
+            if constexpr (NEXT) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sn[i] = 0.f;
+            }
+#define ATT_E(i) sc[i] = __builtin_amdgcn_exp2f(fmaf(sc[i], sc2, -msc))
+#define ATT_QK(ks) if constexpr (NEXT) sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], sn, 0, 0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_QK(0); ATT_E(0); ATT_E(1); ATT_E(2); ATT_E(3);
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_QK(1); ATT_E(4); ATT_E(5); ATT_E(6); ATT_E(7);
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_QK(2);
+            const bf16x8 pf0 = acc_to_bf16(sc, 0);
+            ATT_E(8); ATT_E(9);
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_QK(3); ATT_E(10); ATT_E(11); ATT_E(12); ATT_E(13);
+            __builtin_amdgcn_sched_barrier(0);
+            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pf0, oacc[0], 0, 0, 0);
+            ATT_E(14); ATT_E(15);
+            ps0 += sc[0]; ps1 += sc[1]; ps0 += sc[2]; ps1 += sc[3];
+            __builtin_amdgcn_sched_barrier(0);
+            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, pf0, oacc[1], 0, 0, 0);
+            const bf16x8 pf1 = acc_to_bf16(sc, 1);
+            vf0 = read_tr_frag(Vc, hc, 1, 0, lane); vf1 = read_tr_frag(Vc, hc, 1, 1, lane);
+            ps0 += sc[4]; ps1 += sc[5]; ps0 += sc[6]; ps1 += sc[7];
+            __builtin_amdgcn_sched_barrier(0);
+            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pf1, oacc[0], 0, 0, 0);
+            ps0 += sc[8]; ps1 += sc[9]; ps0 += sc[10]; ps1 += sc[11];
+            __builtin_amdgcn_sched_barrier(0);
+            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, pf1, oacc[1], 0, 0, 0);
+            ps0 += sc[12]; ps1 += sc[13]; ps0 += sc[14]; ps1 += sc[15];
+            __builtin_amdgcn_sched_barrier(0);
+#undef ATT_E
+#undef ATT_QK
+        };
+        f32x16 s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s0[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&Kbuf[0][k_off(r, 2 * ks + hf)], qf[ks], s0, 0, 0, 0);
+        for (int t = 0; t < L; ++t) {
+            const bf16_t* Vs = Vbuf[cur];
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            pipe_step(s0, s1, Kbuf[cur], 1, Vs, 0, kv0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile (issued a tile ago) is in LDS
+            __syncthreads();                                  // ... for every wave, and the tile before this one is free
+            if (kv0 + 128 < kend) dma_tile(kv0 + 128, cur == 0 ? 2 : cur - 1);
+            pipe_step(s1, s0, Kbuf[nxt], 0, Vs, 1, kv0);
+            kv0 += 64; cur = nxt;
+        }
+        lsum += ps0 + ps1;
+    }
+    if constexpr (!PIPE)
+    for (; kv0 < kend; kv0 += 64, cur = (cur + 1 == ATT_NBUF ? 0 : cur + 1)) {
         const bf16_t* Ks = Kbuf[cur];
         const bf16_t* Vs = Vbuf[cur];
         // a later tile lands in the buffer that was last read one barrier ago while this one is computed: with
@@ -988,8 +1092,8 @@ static AttnSplit attn_split_plan(int64_t B, int64_t H, int64_t Tq, int64_t Tk, i
     static int occ[2] = {0, 0};                               // resident workgroups per CU, as the runtime computes it
     if (!occ[dropout]) {
         int n = 0;
-        const hipError_t e = dropout ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<true>, 256, 0)
-                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<false>, 256, 0);
+        const hipError_t e = dropout ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<true, false>, 256, 0)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<false, true>, 256, 0);
         occ[dropout] = (e == hipSuccess && n > 0) ? n : ATT_OCC;
     }
     const int slots = (cus / 8) * occ[dropout];               // resident workgroups per XCD
@@ -1048,12 +1152,17 @@ extern "C" int avsr_attn_fwd_ws(avsr_stream_t stream, int dtype, int use_mfma, c
             pl = AttnSplit{per_xcd * qtiles, 0, 1};
         }
         if (p_drop > 0.f)
-            hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
+            hipLaunchKernelGGL((attn_fwd_mfma_kernel<true, false>), grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                                (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
                                (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, (int)B, causal, pl.whole, pl.nsplit, part_ws,
                                tickets);
+        else if (!key_mask && !causal)                          // the software-pipelined form
+            hipLaunchKernelGGL((attn_fwd_mfma_kernel<false, true>), grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
+                               (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
+                               (int)Tq, (int)Tk, (int)H, scale, 0.f, seed, (int)B, causal, pl.whole, pl.nsplit, part_ws,
+                               tickets);
         else
-            hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
+            hipLaunchKernelGGL((attn_fwd_mfma_kernel<false, false>), grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                                (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
                                (int)Tq, (int)Tk, (int)H, scale, 0.f, seed, (int)B, causal, pl.whole, pl.nsplit, part_ws,
                                tickets);
@@ -1127,8 +1236,8 @@ extern "C" int avsr_attn_bwd(avsr_stream_t stream, int dtype, int use_mfma, cons
 extern "C" int avsr_debug_attn_occupancy(int which) {
     int n = -1;
     hipError_t e = hipSuccess;
-    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<false>, 256, 0);
-    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<true>, 256, 0);
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<false, true>, 256, 0);
+    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<true, false>, 256, 0);
     else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_fp8_kernel, 256, 0);
     return e == hipSuccess ? n : -1;
 }
