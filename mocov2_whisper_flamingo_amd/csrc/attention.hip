@@ -202,15 +202,15 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
         static_assert(!PIPE || (ATT_NBUF == 3 && !DROP), "the pipelined loop needs the three-buffer ring");
         const int L = (kend - kbeg + 63) >> 6;               // tiles; only the last can reach past Tk
         float ps0 = 0.f, ps1 = 0.f;
+        // the reference maximum in the two forms the loop uses, updated only when the reference moves: the softmax
+        // subtracts nmsc = -mrun*scale*log2(e) inside the exponent's fma, and a new maximum is compared with thr
+        float nmsc = 0.f, thr = -INFINITY;
         auto pipe_step = [&](f32x16& sc, f32x16& sn, const bf16_t* Kn, int hn, const bf16_t* Vc, int hc, int tile0) {
-            constexpr bool NEXT = true;       // past the last tile the scores of a stale buffer are computed and dropped
             // loads first: the K fragments of the next sub-tile and the first two V fragments of this one land
-            // while the row maximum is found
+            // while the row maximum is found (past the last tile the scores of a stale buffer are computed and dropped)
             bf16x8 kf[4];
-            if constexpr (NEXT) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8*)&Kn[k_off(32 * hn + r, 2 * ks + hf)];
-            }
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8*)&Kn[k_off(32 * hn + r, 2 * ks + hf)];
             bf16x8 vf0 = read_tr_frag(Vc, hc, 0, 0, lane), vf1 = read_tr_frag(Vc, hc, 0, 1, lane);
             __builtin_amdgcn_sched_barrier(0);
             if (tile0 + 64 > Tk) {                            // block-uniform: the tile that reaches past Tk
@@ -226,23 +226,30 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
             mx = vmax3(mx, sc[10], sc[11]);
             my = vmax3(my, sc[12], sc[13]);
             mx = vmax3(mx, sc[14], sc[15]);
-            mx = vmax3(mx, my, my);
-            mx = max_across_halves(mx);
-            if (__any(mx > mrun + lazy)) {
+            {   // ... and across the wave's halves: one v_permlane32_swap, one v_max3 (no canonicalising v_max)
+                const float m2 = vmax3(mx, my, my);
+                const unsigned u = __builtin_bit_cast(unsigned, m2);
+                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                const float a0 = __builtin_bit_cast(float, (unsigned)sw[0]), a1 = __builtin_bit_cast(float, (unsigned)sw[1]);
+                mx = vmax3(a0, a1, a1);
+            }
+            if (__any(mx > thr)) {                            // rare after the first tiles (lazy reference point)
                 const float mnew = fmaxf(mrun, mx);
                 const float alpha = mnew > mrun ? exp2f((mrun - mnew) * sc2) : 1.0f;
                 mrun = mnew;
+                thr = mrun + lazy;
+                nmsc = mrun == -INFINITY ? 0.f : -(mrun * sc2);
                 lsum *= alpha; ps0 *= alpha; ps1 *= alpha;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
             }
-            const float msc = mrun == -INFINITY ? 0.f : mrun * sc2;
-            if constexpr (NEXT) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sn[i] = 0.f;
-            }
-#define ATT_E(i) sc[i] = __builtin_amdgcn_exp2f(fmaf(sc[i], sc2, -msc))
-#define ATT_QK(ks) if constexpr (NEXT) sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], sn, 0, 0, 0)
+            for (int i = 0; i < 16; ++i) sn[i] = 0.f;
+#define ATT_E(i) sc[i] = __builtin_amdgcn_exp2f(fmaf(sc[i], sc2, nmsc))
+// row sums as opaque single adds: left to itself the compiler packs the two chains into one serial chain of
+// v_pk_add_f32 and sinks it behind the last MFMA, where nothing overlaps it
+#define ATT_ADD(acc, i) asm("v_add_f32 %0, %1, %2" : "=v"(acc) : "v"(acc), "v"(sc[i]))
+#define ATT_QK(ks) sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], sn, 0, 0, 0)
             __builtin_amdgcn_sched_barrier(0);
             ATT_QK(0); ATT_E(0); ATT_E(1); ATT_E(2); ATT_E(3);
             __builtin_amdgcn_sched_barrier(0);
@@ -256,21 +263,22 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
             __builtin_amdgcn_sched_barrier(0);
             oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pf0, oacc[0], 0, 0, 0);
             ATT_E(14); ATT_E(15);
-            ps0 += sc[0]; ps1 += sc[1]; ps0 += sc[2]; ps1 += sc[3];
+            ATT_ADD(ps0, 0); ATT_ADD(ps1, 1); ATT_ADD(ps0, 2); ATT_ADD(ps1, 3);
             __builtin_amdgcn_sched_barrier(0);
             oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, pf0, oacc[1], 0, 0, 0);
             const bf16x8 pf1 = acc_to_bf16(sc, 1);
             vf0 = read_tr_frag(Vc, hc, 1, 0, lane); vf1 = read_tr_frag(Vc, hc, 1, 1, lane);
-            ps0 += sc[4]; ps1 += sc[5]; ps0 += sc[6]; ps1 += sc[7];
+            ATT_ADD(ps0, 4); ATT_ADD(ps1, 5); ATT_ADD(ps0, 6); ATT_ADD(ps1, 7);
             __builtin_amdgcn_sched_barrier(0);
             oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pf1, oacc[0], 0, 0, 0);
-            ps0 += sc[8]; ps1 += sc[9]; ps0 += sc[10]; ps1 += sc[11];
+            ATT_ADD(ps0, 8); ATT_ADD(ps1, 9); ATT_ADD(ps0, 10); ATT_ADD(ps1, 11);
             __builtin_amdgcn_sched_barrier(0);
             oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, pf1, oacc[1], 0, 0, 0);
-            ps0 += sc[12]; ps1 += sc[13]; ps0 += sc[14]; ps1 += sc[15];
+            ATT_ADD(ps0, 12); ATT_ADD(ps1, 13); ATT_ADD(ps0, 14); ATT_ADD(ps1, 15);
             __builtin_amdgcn_sched_barrier(0);
 #undef ATT_E
 #undef ATT_QK
+#undef ATT_ADD
         };
         f32x16 s0, s1;
 #pragma unroll
@@ -278,16 +286,23 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&Kbuf[0][k_off(r, 2 * ks + hf)], qf[ks], s0, 0, 0, 0);
-        for (int t = 0; t < L; ++t) {
-            const bf16_t* Vs = Vbuf[cur];
-            const int nxt = cur == 2 ? 0 : cur + 1;
-            pipe_step(s0, s1, Kbuf[cur], 1, Vs, 0, kv0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile (issued a tile ago) is in LDS
-            __syncthreads();                                  // ... for every wave, and the tile before this one is free
-            if (kv0 + 128 < kend) dma_tile(kv0 + 128, cur == 0 ? 2 : cur - 1);
-            pipe_step(s1, s0, Kbuf[nxt], 0, Vs, 1, kv0);
-            kv0 += 64; cur = nxt;
+        // one tile: buffer indices are compile-time constants (the ring is walked by an unrolled-by-three loop), so
+        // every LDS address of the fragment reads is a loop-invariant register plus an immediate offset
+#define ATT_PIPE_TILE(CUR)                                                                                     \
+        {                                                                                                          \
+            pipe_step(s0, s1, Kbuf[CUR], 1, Vbuf[CUR], 0, kv0);                                                    \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the next tile (issued a tile ago) is in LDS */      \
+            __syncthreads();                    /* ... for every wave, and the tile before this one is free */     \
+            if (kv0 + 128 < kend) dma_tile(kv0 + 128, ((CUR) + 2) % 3);                                            \
+            pipe_step(s1, s0, Kbuf[((CUR) + 1) % 3], 0, Vbuf[CUR], 1, kv0);                                        \
+            kv0 += 64;                                                                                             \
         }
+        for (int t = 0; t < L; t += 3) {
+            ATT_PIPE_TILE(0)
+            if (t + 1 < L) ATT_PIPE_TILE(1)
+            if (t + 2 < L) ATT_PIPE_TILE(2)
+        }
+#undef ATT_PIPE_TILE
         lsum += ps0 + ps1;
     }
     if constexpr (!PIPE)
