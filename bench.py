@@ -398,14 +398,18 @@ def main():
         achieved = fsum / tsum / 1e12
         # HBM bytes per launch of the same kernel come from separate rocprofv3 --pmc passes over this command
         # (a profiler has to wrap the process); the committed summary is read back here
-        traffic = None
+        # (the counters see every launch of the kernel, including the 25 small products the fused cross-attention
+        # blocks launch from C, which the event timing above cannot bracket one by one: traffic_launches says so)
+        traffic, traffic_launches = None, None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as fh:
-                traffic = round(float(json.load(fh)["hbm_bytes_per_launch"]))
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")) as fh:
+                rec = json.load(fh)
+            traffic, traffic_launches = round(float(rec["hbm_bytes_per_launch"])), int(rec["launches"])
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_launches": traffic_launches,
                     "kernel": "gemm_bf16_kernel (dense + implicit-GEMM conv instantiations)",
                     "launches_per_step": len(recs), "avg_launch_us": round(tsum / len(recs) * 1e6, 2),
                     "algorithmic_gflop_per_step": round(fsum / 1e9, 1),

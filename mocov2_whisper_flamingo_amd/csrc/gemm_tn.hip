@@ -6,6 +6,7 @@
 // comes out of the same pass.  One 64 x 64 tile of C per workgroup, four waves of one v_mfma_f32_32x32x16_bf16
 // accumulator each.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -49,13 +50,15 @@ template <int TB, int NST>
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                            long ldb, float* __restrict__ C, long ldc, int M, int N, int K,
                                                            int accumulate, float* __restrict__ colsum, int accumulate_colsum,
-                                                           int ntiles, int ktiles) {
+                                                           int ntiles, int ktiles, int nsplit) {
     constexpr int TILE = 64 * TB, SUB = 64 * 64;              // an operand stage is TB sub-tiles of [64 rows][64 cols]
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     bf16_t* As = (bf16_t*)lds_raw;                            // [NST][TB][SUB]
     bf16_t* Bs = As + NST * TB * SUB;
     float* csum = (float*)(lds_raw + tn_main_bytes<TB, NST>());   // [4][TILE], behind the stages / the epilogue blocks
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    // nsplit > 1 (long contractions into few tiles): the rows are cut into nsplit shares, one workgroup each, and
+    // the shares meet in C and colsum by fp32 atomic adds (accumulating calls only; summation order then varies)
+    const int xcd = blockIdx.x & 7, j = (blockIdx.x >> 3) / nsplit, part = (blockIdx.x >> 3) - j * nsplit;
     const int kt = j % ktiles, nt = (j / ktiles) * 8 + xcd;
     if (nt >= ntiles) return;
     const int n0 = nt * TILE, k0 = kt * TILE;
@@ -64,9 +67,34 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
     const int prow = lane >> 3, pch = lane & 7;
     const uintptr_t zaddr = (uintptr_t)tn_zero_page;
 
-    // a wave moves pieces 2*wave and 2*wave + 1 (8 rows each) of every sub-tile; a chunk outside the matrix (row >= M,
-    // or its 8 columns not inside the row pitch) reads the zero page instead.  4*TB instructions per wave and stage.
+    // A wave moves pieces 2*wave and 2*wave + 1 (8 rows each) of every sub-tile: 4*TB instructions per wave and stage.
+    // Interior stages (all 64 rows < M, the tile's columns inside both matrices) use the scalar-base form of the
+    // instruction through inline asm: the compiler does not know these loads, so it puts no wait between them and
+    // the fragment reads of the stage being computed (behind the builtin it waits for vmcnt(0) at once, which turns
+    // the ring into load - wait - compute).  Edge stages go through the builtin with a per-lane address, where a chunk
+    // outside the matrix (row >= M, or its 8 columns not inside the row pitch) reads the zero page instead.
+    unsigned offA[2], offB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = (2 * wave + i) * 8 + prow;
+        const int ch = pch ^ (((rr >> 1) & 1) << 2);
+        offA[i] = (unsigned)(((long)rr * lda + ch * 8) * 2);
+        offB[i] = (unsigned)(((long)rr * ldb + ch * 8) * 2);
+    }
+    const bool cols_inside = n0 + TILE <= N && k0 + TILE <= K;
     auto dma_tiles = [&](int m0, int buf) {
+        if (cols_inside && m0 + 64 <= M) {
+            const char* ab = (const char*)(A + (long)m0 * lda + n0);
+            const char* bb = (const char*)(B + (long)m0 * ldb + k0);
+#pragma unroll
+            for (int sub = 0; sub < TB; ++sub)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    dma_piece(ab + 128 * sub, offA[i], (const char*)&As[(buf * TB + sub) * SUB + (2 * wave + i) * 512]);
+                    dma_piece(bb + 128 * sub, offB[i], (const char*)&Bs[(buf * TB + sub) * SUB + (2 * wave + i) * 512]);
+                }
+            return;
+        }
 #pragma unroll
         for (int sub = 0; sub < TB; ++sub)
 #pragma unroll
@@ -105,14 +133,16 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
     // wave -> a TB x TB group of 32 x 32 blocks: rows (N) 32*TB*(wave & 1) .., columns (K) 32*TB*(wave >> 1) ..
     const int nb0 = TB * (wave & 1), kb0 = TB * (wave >> 1);
     const bool sums = colsum != nullptr && kt == 0;
-    const int nsteps = (M + 63) >> 6;
-    dma_tiles(0, 0);
-    if (NST > 2 && nsteps > 1) dma_tiles(64, 1);
+    const int allsteps = (M + 63) >> 6;
+    const int st0 = (int)((long)part * allsteps / nsplit), nsteps = (int)((long)(part + 1) * allsteps / nsplit) - st0;
+    const int mbase = 64 * st0;
+    dma_tiles(mbase, 0);
+    if (NST > 2 && nsteps > 1) dma_tiles(mbase + 64, 1);
     wait_oldest(nsteps > 1);
     __syncthreads();
     for (int st = 0, cur = 0; st < nsteps; ++st, cur = (cur + 1 == NST ? 0 : cur + 1)) {
         const int ahead = st + NST - 1;                       // its buffer was last read one barrier ago
-        if (ahead < nsteps) dma_tiles(64 * ahead, cur == 0 ? NST - 1 : cur - 1);
+        if (ahead < nsteps) dma_tiles(mbase + 64 * ahead, cur == 0 ? NST - 1 : cur - 1);
         const bf16_t* as = As + cur * TB * SUB;
         const bf16_t* bs = Bs + cur * TB * SUB;
 #pragma unroll
@@ -163,7 +193,9 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
         if (n >= N || kq >= K) continue;
         const f32x4 v = *(const f32x4*)&ct[row * LDT + qc];
         float* cp = C + (long)n * ldc + kq;
-        if (vec && kq + 4 <= K) {
+        if (nsplit > 1) {
+            for (int e = 0; e < 4 && kq + e < K; ++e) unsafeAtomicAdd(cp + e, v[e]);      // the hardware fp32 add, no CAS loop
+        } else if (vec && kq + 4 <= K) {
             f32x4 o = v;
             if (accumulate) { const f32x4 c = *(const f32x4*)cp; o[0] += c[0]; o[1] += c[1]; o[2] += c[2]; o[3] += c[3]; }
             *(f32x4*)cp = o;
@@ -177,7 +209,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
         __syncthreads();
         if (t < TILE && n0 + t < N) {
             const float s = csum[t] + csum[TILE + t] + csum[2 * TILE + t] + csum[3 * TILE + t];
-            colsum[n0 + t] = accumulate_colsum ? colsum[n0 + t] + s : s;
+            if (nsplit > 1) unsafeAtomicAdd(&colsum[n0 + t], s);
+            else colsum[n0 + t] = accumulate_colsum ? colsum[n0 + t] + s : s;
         }
     }
 }
@@ -195,11 +228,17 @@ int launch_tn(hipStream_t s, const void* A, int64_t lda, const void* B, int64_t 
         attr_set = true;
     }
     const int64_t ntiles = (N + 64 * TB - 1) / (64 * TB), ktiles = (K + 64 * TB - 1) / (64 * TB);
-    const int64_t grid = 8 * ((ntiles + 7) / 8) * ktiles;
+    // Few tiles and a very long contraction (thousands of rows): several workgroups per tile, each at least 32
+    // 64-row steps, meeting in C by atomic adds (1.7x at M = 12000 into 768 x 768; at 3200 rows the atomics cost what
+    // the shorter loops save).  The tail's own shapes (hundreds of rows) never split: their sums stay order-exact.
+    int64_t nsplit = 1;
+    if (accumulate && (!colsum || accumulate_colsum))
+        nsplit = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((M + 63) / 64 / 32, 512 / (ntiles * ktiles)), 16));
+    const int64_t grid = 8 * ((ntiles + 7) / 8) * ktiles * nsplit;
     if (grid > 0x7fffffff) return AVSR_EUNSUPPORTED;
     hipLaunchKernelGGL((gemm_tn_bf16_kernel<TB, NST>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)A, (long)lda,
                        (const bf16_t*)B, (long)ldb, C, (long)ldc, (int)M, (int)N, (int)K, accumulate, colsum,
-                       accumulate_colsum, (int)ntiles, (int)ktiles);
+                       accumulate_colsum, (int)ntiles, (int)ktiles, (int)nsplit);
     return avsr_launch_status();
 }
 
@@ -212,9 +251,10 @@ extern "C" int avsr_gemm_tn(avsr_stream_t stream, const void* A, int64_t lda, co
     if (lda < N || ldb < K || ldc < K) return AVSR_EINVAL;
     if (lda % 8 || ldb % 8 || ((uintptr_t)A | (uintptr_t)B) % 16) return AVSR_EUNSUPPORTED;
     if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return AVSR_EUNSUPPORTED;
+    if (64 * std::max(lda, ldb) * 2 > 0x7fffffffLL) return AVSR_EUNSUPPORTED;       // 32-bit byte offsets inside a stage
     hipStream_t s = (hipStream_t)stream;
     // thousands of 64 x 64 tiles (the vocabulary head): 128 x 128 tiles halve the operand traffic out of L2
     if (((N + 63) / 64) * ((K + 63) / 64) >= 2048)
         return launch_tn<2, 2>(s, A, lda, B, ldb, C, ldc, M, N, K, accumulate, colsum, accumulate_colsum);
-    return launch_tn<1, 2>(s, A, lda, B, ldb, C, ldc, M, N, K, accumulate, colsum, accumulate_colsum);
+    return launch_tn<1, 3>(s, A, lda, B, ldb, C, ldc, M, N, K, accumulate, colsum, accumulate_colsum);
 }

@@ -11,7 +11,7 @@ def timeit(fn, n=30):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for M, N, K in [(64, 512, 512), (128, 512, 512), (600, 512, 512), (1200, 512, 512), (2400, 512, 512), (600, 2048, 512),
+for M, N, K in [(64, 512, 512), (128, 512, 512), (600, 512, 512), (1200, 512, 512), (2400, 512, 512), (600, 2048, 512), (3200, 512, 512), (3200, 2048, 512), (3200, 512, 2048), (12000, 768, 768),
                 (600, 512, 2048), (64, 51865, 512), (600, 51865, 512)]:
     ldn = (N + 7) // 8 * 8
     dy = torch.randn(M, ldn, device=dev).to(torch.bfloat16)[:, :N]

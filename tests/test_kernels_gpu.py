@@ -220,7 +220,7 @@ def test_attn_mfma_fwd(dev, Tq, Tk):
 
 
 @pytest.mark.parametrize("M,N,K", [(600, 512, 512), (600, 2048, 512), (600, 51865, 512), (75, 100, 72), (1, 64, 64),
-                                   (1000, 520, 2048)])
+                                   (1000, 520, 2048), (3200, 512, 512), (5000, 200, 136), (12000, 768, 768)])
 def test_gemm_tn_weight_gradient(dev, M, N, K):
     """dW = dY^T X and db = column sums of dY from the row-major operands (no transposed copies), written or
     accumulated; ragged M / N / K and a padded row pitch (N = 51865 in rows of 51872)."""
