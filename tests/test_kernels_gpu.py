@@ -195,7 +195,7 @@ def _attn_ref(q, k, v, H, mask, scale, keep=None, p=0.0):
     return (pr @ vh).transpose(1, 2).reshape(B, Tq, H * 64)
 
 
-@pytest.mark.parametrize("Tq,Tk", [(1500, 1500), (75, 75), (130, 257)])
+@pytest.mark.parametrize("Tq,Tk", [(1500, 1500), (75, 75), (130, 257), (20, 20), (64, 64), (33, 100), (200, 129)])
 def test_attn_mfma_fwd(dev, Tq, Tk):
     g = torch.Generator().manual_seed(Tq)
     B, H = 2, 3
