@@ -52,6 +52,26 @@ def test_whisper_encoder_at_benchmark_widths(dev, dtype, name, layers):
     assert max_err(got, ref) < TOL[dtype]
 
 
+def test_whisper_encoder_batch_8_with_split_attention_rounds(dev):
+    """Whisper-small at the benchmark batch (8 clips: 1152 attention items on 768 resident workgroups).  With
+    ``attn_split`` the items of the half-empty last round are computed by two workgroups each and merged; the encoder
+    output must agree with the unsplit run to bf16 rounding, call after call on the same workspace."""
+    full = WhisperConfig.from_name("small")
+    cfg = WhisperConfig(d_model=full.d_model, encoder_layers=2, encoder_attention_heads=full.encoder_attention_heads,
+                        with_decoder=False)
+    m = WhisperModel(cfg)
+    seed_module(m, 9)
+    m.to(dev)
+    mel = torch.randn(8, 80, 3000, generator=torch.Generator().manual_seed(4)).to(dev)
+    base = m.encoder(mel, dtype=torch.bfloat16)[0]
+    m.encoder.attn_split = True
+    for _ in range(2):
+        got = m.encoder(mel, dtype=torch.bfloat16)[0]
+        assert m.encoder._attn_ws._buf is not None, "this shape is split"
+        assert max_err(got, base) < 1e-2
+    assert bool((m.encoder._attn_ws._buf[:4 * 384] == 0).all()), "the 384 counters come back to zero"
+
+
 @pytest.mark.parametrize("dtype,training", [(torch.float32, False), (torch.bfloat16, False), (torch.float32, True),
                                             (torch.bfloat16, True)])
 def test_visual_frontend_full_clip(dev, dtype, training):
