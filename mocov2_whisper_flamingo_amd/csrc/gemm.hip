@@ -825,8 +825,9 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     // quarter of the chip idle while 52 CUs run a third tile; 750 tiles of 96 rows are 2.93 per CU).
     int bm = G_BM;
     if (small) bm = 64;
-    if (bf && !conv && !g->col_sum && bn == 128 && g->batch == 1 && !p.ext) {
-        const long tn = (p.N + 127) / 128;
+    if (bf && !conv && !g->col_sum && bn == 128 && !p.ext) {
+        // batched products (the Whisper stem convolutions, one batch per clip) count every batch's tiles
+        const long tn = ((p.N + 127) / 128) * std::max<long>(1, g->batch);
         const long t128 = ((p.M + 127) / 128) * tn, t96 = ((p.M + 95) / 96) * tn;
         auto fill = [](long t, long rows, long M, long tnn) {      // useful rows / rows the busiest CU's rounds pay for
             const long rounds = (t + G_NUM_CU - 1) / G_NUM_CU;
