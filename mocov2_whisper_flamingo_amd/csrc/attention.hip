@@ -84,9 +84,6 @@ template <bool DROP, bool PIPE>
 #ifndef ATT_LAZY_LOG2
 #define ATT_LAZY_LOG2 8.0f
 #endif
-#ifndef ATT_PIPE
-#define ATT_PIPE 1
-#endif
 #ifndef ATT_NBUF
 #define ATT_NBUF 3
 #endif
