@@ -108,12 +108,13 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __forceinline__ float gelu_erf_fast(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(t, 1.061405429f, -1.453152027f);
-    poly = fmaf(t, poly, 1.421413741f);
-    poly = fmaf(t, poly, -0.284496736f);
-    poly = fmaf(t, poly, 0.254829592f);
-    const float q = 0.5f * poly * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // erfc(z) / 2
-    return x * (x < 0.f ? q : 1.0f - q);
+    float poly = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);        // the polynomial of erfc(z) / 2
+    poly = fmaf(t, poly, 0.5f * 1.421413741f);
+    poly = fmaf(t, poly, 0.5f * -0.284496736f);
+    poly = fmaf(t, poly, 0.5f * 0.254829592f);
+    const float q = poly * t * __builtin_amdgcn_exp2f(-0.72134752044448170368f * (x * x));   // erfc(z) / 2 = Phi(-|x|)
+    // x Phi(x) = max(x, 0) - |x| Phi(-|x|) for either sign: no compare / select
+    return fmaf(-fabsf(x), q, fmaxf(x, 0.f));
 }
 // d/dx of gelu_erf
 __device__ __forceinline__ float gelu_erf_grad(float x) {
