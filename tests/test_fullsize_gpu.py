@@ -70,6 +70,13 @@ def test_whisper_encoder_batch_8_with_split_attention_rounds(dev):
         assert m.encoder._attn_ws._buf is not None, "this shape is split"
         assert max_err(got, base) < 1e-2
     assert bool((m.encoder._attn_ws._buf[:4 * 384] == 0).all()), "the 384 counters come back to zero"
+    # the pruned last layer (75 queries per clip over 1500 keys: 96 items, every one cut four ways)
+    m.encoder.attn_split = False
+    base = m.encoder(mel, dtype=torch.bfloat16, rows=75)[0]
+    m.encoder.attn_split = True
+    got = m.encoder(mel, dtype=torch.bfloat16, rows=75)[0]
+    assert got.shape == base.shape == (8, 75, full.d_model)
+    assert max_err(got, base) < 1e-2
 
 
 @pytest.mark.parametrize("dtype,training", [(torch.float32, False), (torch.bfloat16, False), (torch.float32, True),
