@@ -159,7 +159,12 @@ int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, 
  * workspace: 256-byte aligned, at least avsr_attn_fwd_workspace_bytes(...) bytes (0 = this shape is not split);
  * its first ceil(4*items/256)*256 bytes are counters that must be ZERO before the first call and are left zero by
  * every call, so one buffer zeroed once serves a whole stream of calls; calls that share a workspace must not
- * overlap.  workspace == NULL or too small: exactly avsr_attn_fwd. */
+ * overlap.  workspace == NULL or too small: exactly avsr_attn_fwd.
+ * The split is only offered on the full 256-CU / 8-XCD device the workgroup-id mapping was measured on (all shares
+ * of an item have equal blockIdx & 7, i.e. share one XCD's L2 under round-robin placement; the shares themselves
+ * travel by system-scope stores and loads, so the sum does not depend on that placement): on any other device or
+ * CU partition avsr_attn_fwd_workspace_bytes returns 0 and the call runs unsplit.  The current device must be the
+ * stream's device. */
 int64_t avsr_attn_fwd_workspace_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk, float p_drop, int causal);
 int avsr_attn_fwd_ws(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
                      int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
@@ -248,7 +253,10 @@ int avsr_logmel_fwd(avsr_stream_t stream, int variant, int out_dtype, const floa
  * every GPU the library runs on holds one copy until the process ends.  The call allocates nothing; it returns
  * AVSR_EUNSUPPORTED when avsr_logmel_workspace_floats(batch, n_frames_out) exceeds AVSR_LOGMEL_STATIC_FLOATS
  * (8 clips of 30 s fit).  All calls on one GPU share that GPU's array: calls that may overlap on one GPU (two
- * streams, two threads) race - order them on one stream.  Results are bit-identical to avsr_logmel_fwd. */
+ * streams, two threads) race - order them on one stream.  Results are bit-identical to avsr_logmel_fwd.
+ * The array used is the CURRENT device's, so the current device must be the one `stream` belongs to: a stream
+ * of another device is refused with AVSR_EINVAL (checked with hipStreamGetDevice; the NULL stream is the current
+ * device's).  Devices numbered 64 and up are not served (AVSR_EUNSUPPORTED). */
 #define AVSR_LOGMEL_STATIC_FLOATS (2 * 1024 * 1024)
 int avsr_logmel_fwd_static(avsr_stream_t stream, int variant, int out_dtype, const float* wave, int64_t wave_stride,
                            int64_t n_samples, int64_t n_valid, int64_t batch, const float* dft_table,

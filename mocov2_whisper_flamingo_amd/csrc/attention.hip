@@ -1092,25 +1092,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_valu_kernel(const T* __restr
 // the chip's resident-workgroup slots empty; it needs the caller's workspace, no causal mask, and at least four key
 // tiles per share.
 struct AttnSplit { int whole, rest, nsplit; };
+// Invariant the merge relies on for speed, not for correctness of a single share: every share of an item has the same
+// blockIdx & 7, i.e. (under the round-robin placement of workgroups over 8 XCDs) the same XCD and L2.  The shares are
+// exchanged with system-scope stores and loads, which go through to memory on any placement; the plan below is only
+// offered on the 256-CU / 8-XCD layout the id mapping was measured on, any other device or partition runs unsplit.
 static AttnSplit attn_split_plan(int64_t B, int64_t H, int64_t Tq, int64_t Tk, int causal, bool dropout) {
     const int per_xcd = (int)((B * H + 7) / 8), qtiles = (int)((Tq + 127) / 128), items = per_xcd * qtiles;
     AttnSplit pl{items, 0, 1};
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = n;
-        if (cus <= 0) cus = 256;
+    constexpr int MAXDEV = 64;
+    static int cus_of[MAXDEV];                                // per device: CU count and resident workgroups per CU
+    static int occ_of[MAXDEV][2];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return pl;
+    if (!cus_of[dev]) {
+        int n = 0;
+        cus_of[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : -1;
     }
-    static int occ[2] = {0, 0};                               // resident workgroups per CU, as the runtime computes it
-    if (!occ[dropout]) {
+    if (!occ_of[dev][dropout]) {
         int n = 0;
         const hipError_t e = dropout ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<true, false>, 256, 0)
                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<false, true>, 256, 0);
-        occ[dropout] = (e == hipSuccess && n > 0) ? n : ATT_OCC;
+        occ_of[dev][dropout] = (e == hipSuccess && n > 0) ? n : ATT_OCC;
     }
-    const int slots = (cus / 8) * occ[dropout];               // resident workgroups per XCD
+    const int cus = cus_of[dev];
+    if (cus != 256 || causal) return pl;                      // not the 8-XCD layout (or a partition of it): no split
+    const int slots = (cus / 8) * occ_of[dev][dropout];       // resident workgroups per XCD
+    if (slots <= 0) return pl;
     const int rem = items % slots;
-    if (causal || rem == 0 || slots <= 0) return pl;
+    if (rem == 0) return pl;
     const int ns = std::min<int>(std::min<int>(4, slots / rem), (int)((Tk + 63) / 64 / 4));
     if (ns < 2) return pl;
     pl.whole = items - rem; pl.rest = rem; pl.nsplit = ns;

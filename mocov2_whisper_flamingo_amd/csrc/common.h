@@ -22,6 +22,21 @@ static inline int avsr_launch_status() {
     return e == hipSuccess ? AVSR_OK : AVSR_EHIP;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device).
+// `done` is the call site's own zero-initialised table (one per kernel instantiation); a racing second thread at
+// worst sets the idempotent attribute twice.
+#define AVSR_MAX_DEVICES 64
+struct avsr_dev_flags { bool set[AVSR_MAX_DEVICES]; };
+static inline bool avsr_allow_lds(const void* kernel, int bytes, avsr_dev_flags& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const bool tracked = dev >= 0 && dev < AVSR_MAX_DEVICES;
+    if (tracked && done.set[dev]) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    if (tracked) done.set[dev] = true;
+    return true;
+}
+
 // Butterfly reductions over the 64 lanes without the LDS crossbar: xor 1 / 2 by quad permutes, 8- and 16-lane sums by
 // the half-row and row mirrors (after the quad steps every quad is uniform, so a mirror pairs the right partners),
 // xor 16 / 32 by v_permlane16_swap / v_permlane32_swap.  Every lane ends with the full result.

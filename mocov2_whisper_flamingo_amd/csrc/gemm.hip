@@ -857,38 +857,26 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
 #define LAUNCH(K, CV, OT) hipLaunchKernelGGL((K<CV, OT>), grid, block, 0, s, p)
 #define LAUNCHB(BNV, NSTV, CV, OT)                                                                             \
     do {                                                                                                       \
-        static bool attr_set = false;                                                                          \
+        static avsr_dev_flags attr_set;                                                                        \
         constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV>();                                                 \
         auto kfn = gemm_bf16_kernel<BNV, NSTV, CV, OT>;                                                        \
-        if (!attr_set) {                                                                                       \
-            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)   \
-                != hipSuccess) return AVSR_EHIP;                                                               \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
+        if (!avsr_allow_lds((const void*)kfn, lds_bytes, attr_set)) return AVSR_EHIP;                          \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
     } while (0)
 #define LAUNCHBM(BNV, NSTV, OT, BMV)                                                                           \
     do {                                                                                                       \
-        static bool attr_set = false;                                                                          \
+        static avsr_dev_flags attr_set;                                                                        \
         constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV, BMV>();                                            \
         auto kfn = gemm_bf16_kernel<BNV, NSTV, 0, OT, BMV>;                                                \
-        if (!attr_set) {                                                                                       \
-            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)   \
-                != hipSuccess) return AVSR_EHIP;                                                               \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
+        if (!avsr_allow_lds((const void*)kfn, lds_bytes, attr_set)) return AVSR_EHIP;                          \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
     } while (0)
 #define LAUNCHX(BNV, NSTV, OT, BMV)                                                                            \
     do {                                                                                                       \
-        static bool attr_set = false;                                                                          \
+        static avsr_dev_flags attr_set;                                                                        \
         constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV, BMV>();                                            \
         auto kfn = gemm_bf16_kernel<BNV, NSTV, 0, OT, BMV, true>;                                              \
-        if (!attr_set) {                                                                                       \
-            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)   \
-                != hipSuccess) return AVSR_EHIP;                                                               \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
+        if (!avsr_allow_lds((const void*)kfn, lds_bytes, attr_set)) return AVSR_EHIP;                          \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
     } while (0)
 #define LAUNCH_CV_OT(BNV, NSTV)                                                                                \

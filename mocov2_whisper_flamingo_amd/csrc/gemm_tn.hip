@@ -220,13 +220,8 @@ template <int TB, int NST>
 int launch_tn(hipStream_t s, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
               int64_t N, int64_t K, int accumulate, float* colsum, int accumulate_colsum) {
     constexpr int lds = tn_lds_bytes<TB, NST>();
-    static bool attr_set = false;                             // per process; the attribute is idempotent
-    if (lds > 48 * 1024 && !attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<TB, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess)
-            return AVSR_EHIP;
-        attr_set = true;
-    }
+    static avsr_dev_flags attr_set;                           // per device; the attribute is idempotent
+    if (lds > 48 * 1024 && !avsr_allow_lds((const void*)gemm_tn_bf16_kernel<TB, NST>, lds, attr_set)) return AVSR_EHIP;
     const int64_t ntiles = (N + 64 * TB - 1) / (64 * TB), ktiles = (K + 64 * TB - 1) / (64 * TB);
     // Few tiles and a very long contraction (thousands of rows): several workgroups per tile, each at least 32
     // 64-row steps, meeting in C by atomic adds (1.7x at M = 12000 into 768 x 768; at 3200 rows the atomics cost what

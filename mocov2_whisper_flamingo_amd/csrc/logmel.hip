@@ -412,10 +412,17 @@ constexpr int LM_MAX_DEVICES = 64;
 std::mutex scratch_mutex;
 float* scratch_ptr[LM_MAX_DEVICES] = {};
 
-// address of the current device's copy of `scratch` (looked up once per device), or nullptr
-float* logmel_static_scratch() {
+// address of the current device's copy of `scratch` (looked up once per device); nullptr + *status on failure
+float* logmel_static_scratch(hipStream_t stream, int* status) {
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LM_MAX_DEVICES) return nullptr;
+    *status = AVSR_EHIP;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+    if (dev >= LM_MAX_DEVICES) { *status = AVSR_EUNSUPPORTED; return nullptr; }
+    if (stream) {                                             // the kernels run on the stream's device: it has to be this one
+        int sdev = -1;
+        if (hipStreamGetDevice(stream, &sdev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (sdev != dev) { *status = AVSR_EINVAL; return nullptr; }
+    }
     std::lock_guard<std::mutex> lock(scratch_mutex);
     if (!scratch_ptr[dev]) {
         void* p = nullptr;
@@ -445,12 +452,23 @@ extern "C" int avsr_logmel_fwd_static(avsr_stream_t stream, int variant, int out
     if (batch <= 0 || n_frames_out <= 0) return AVSR_EINVAL;
     if (batch > 65535 || n_frames_out > AVSR_LOGMEL_STATIC_FLOATS) return AVSR_EUNSUPPORTED;
     if (avsr_logmel_workspace_floats(batch, n_frames_out) > AVSR_LOGMEL_STATIC_FLOATS) return AVSR_EUNSUPPORTED;
-    float* ws = logmel_static_scratch();
-    if (!ws) return AVSR_EHIP;
+    int status = AVSR_EHIP;
+    float* ws = logmel_static_scratch((hipStream_t)stream, &status);
+    if (!ws) return status;
     // every word of the workspace the finalize kernel reads is written by the first kernel of the same call,
     // so nothing of the previous call's contents has to be cleared
     return logmel_fwd_impl(stream, variant, out_dtype, wave, wave_stride, n_samples, n_valid, batch, dft_table,
                            mel_table, out, out_stride_b, out_stride_t, out_stride_m, n_frames_out, ws);
+}
+
+// Debugging aid (not part of the declared interface): overwrite the current device's static scratch with 0xFF bytes
+// (every float a NaN), so a test can show that a call reads nothing an earlier call left there.
+extern "C" int avsr_debug_logmel_static_poison(avsr_stream_t stream) {
+    int status = AVSR_EHIP;
+    float* ws = logmel_static_scratch((hipStream_t)stream, &status);
+    if (!ws) return status;
+    return hipMemsetAsync(ws, 0xFF, sizeof(float) * (size_t)AVSR_LOGMEL_STATIC_FLOATS, (hipStream_t)stream) == hipSuccess
+               ? AVSR_OK : AVSR_EHIP;
 }
 
 extern "C" int64_t avsr_logmel_augment_workspace_floats(int64_t batch, int64_t n_frames_out) {

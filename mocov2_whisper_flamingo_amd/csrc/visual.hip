@@ -610,12 +610,8 @@ extern "C" int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float*
     const int rows = stem_mfma_rows(W, &lds);
     if (out_dtype == AVSR_BF16 && weight_frags && rows > 0 && (W % 4) == 0 && (uintptr_t)video % 16 == 0) {
         if ((uintptr_t)weight_frags % 16 || (uintptr_t)out % 8) return AVSR_EUNSUPPORTED;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)stem3d_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
-                != hipSuccess) return AVSR_EHIP;
-            attr_set = true;
-        }
+        static avsr_dev_flags attr_set;
+        if (!avsr_allow_lds((const void*)stem3d_mfma_kernel, 96 * 1024, attr_set)) return AVSR_EHIP;
         const long nitems = B * ((T + SM_F - 1) / SM_F) * ((OH + rows - 1) / rows);
         const unsigned nblk = (unsigned)(nitems < 512 ? nitems : 512);      // persistent: two workgroups per CU
         hipLaunchKernelGGL(stem3d_mfma_kernel, dim3(nblk), dim3(256), lds, s, video, (const bf16_t*)weight_frags,
@@ -688,12 +684,8 @@ extern "C" int avsr_video_color(avsr_stream_t stream, float* video, int64_t B, i
     if (std3[0] == 0.f || std3[1] == 0.f || std3[2] == 0.f) return AVSR_EINVAL;
     const size_t lds = (size_t)3 * H * W * sizeof(float);
     if (lds > 150 * 1024 || B * T > 0x7fffffff) return AVSR_EUNSUPPORTED;       // a frame's three planes live in LDS
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)video_color_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
-            hipSuccess) return AVSR_EHIP;
-        attr_set = true;
-    }
+    static avsr_dev_flags attr_set;
+    if (!avsr_allow_lds((const void*)video_color_kernel, 150 * 1024, attr_set)) return AVSR_EHIP;
     hipLaunchKernelGGL(video_color_kernel, dim3((unsigned)(B * T)), dim3(256), lds, (hipStream_t)stream, video, (int)T,
                        (int)(H * W), order, factors, grey, frame_zero, mean3[0], mean3[1], mean3[2], 1.f / std3[0],
                        1.f / std3[1], 1.f / std3[2]);

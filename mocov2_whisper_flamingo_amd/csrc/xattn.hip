@@ -60,7 +60,9 @@ BwdLayout bwd_layout(const avsr_xattn_block_t* b) {
     L.dy = take(M * d * es); L.dh = take(M * d * es); L.dx1 = take(M * d * es); L.dao = take(M * d * es);
     L.dq = take(M * d * es); L.dkv = take(Mk * 2 * d * es); L.du = take(M * dff * es);
     L.dws = take((size_t)(b->B * b->H * b->Tq) * 4);
-    L.tA = take(dff * Rp * es); L.tB = take(dff * Rp * es);           // transposed operands of the dW products
+    // transposed operands of the dW products: the widest one is dff rows (fc1 / fc2) or 2*d rows (the K|V projection)
+    const size_t tw = dff > 2 * d ? dff : 2 * d;
+    L.tA = take(tw * Rp * es); L.tB = take(tw * Rp * es);
     L.total = o;
     return L;
 }

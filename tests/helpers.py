@@ -81,3 +81,42 @@ def to_device(batch, dev):
 def max_err(got, ref):
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     return ((got - ref).abs().max() / ref.abs().max().clamp_min(1.0)).item()
+
+
+# ---- closeness beyond the global-scale maximum ------------------------------------------------------------------
+# max_err divides by the tensor's largest magnitude, so an element a hundred times smaller than that maximum may be
+# entirely wrong and still pass.  assert_close adds two scale-aware criteria: the relative L2 error of the whole
+# tensor (limit tol / 2: the bf16 Whisper-small encoder measures 5.3e-3 against tol = 2e-2, fp32 paths 1e-6 against
+# 1e-3), and the share of elements whose own error exceeds tol * (|ref| + rms(ref)).  Every call is recorded in
+# PARITY_REPORT (printed at the end of the session by conftest.py).  AVSR_PARITY_SOFT=1 records without asserting
+# the two added criteria (used to survey all tests in one run).
+import os
+
+PARITY_REPORT = []
+
+
+def closeness(got, ref, tol):
+    got, ref = got.detach().float().cpu().reshape(-1), ref.detach().float().cpu().reshape(-1)
+    diff = (got - ref).abs()
+    rms = ref.pow(2).mean().sqrt().clamp_min(1e-30)
+    return {"max_err": (diff.max() / ref.abs().max().clamp_min(1.0)).item(),
+            "rel_l2": (diff.pow(2).sum().sqrt() / ref.pow(2).sum().sqrt().clamp_min(1e-30)).item(),
+            "outliers": (diff > tol * (ref.abs() + rms)).float().mean().item()}
+
+
+def assert_close(got, ref, tol, what, l2_div=2.0, max_outliers=1e-3):
+    """max |diff| / max(1, max |ref|) < tol, relative L2 error <= tol / l2_div, and at most max_outliers of the
+    elements off by more than tol * (|ref| + rms(ref))."""
+    c = closeness(got, ref, tol)
+    PARITY_REPORT.append({"what": what, "tol": tol, "l2_limit": tol / l2_div, "outlier_limit": max_outliers, **c})
+    assert c["max_err"] < tol, (what, c)
+    if os.environ.get("AVSR_PARITY_SOFT") == "1":
+        return c
+    assert c["rel_l2"] <= tol / l2_div, (what, c)
+    assert c["outliers"] <= max_outliers, (what, c)
+    return c
+
+
+def record(what, **values):
+    """A measured figure that is reported, not asserted (e.g. an agreement rate)."""
+    PARITY_REPORT.append({"what": what, **values})

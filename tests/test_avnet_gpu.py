@@ -10,7 +10,7 @@ import torch
 
 import oracle
 from mocov2_whisper_flamingo_amd import AVNet, GatedCrossModalFusion, MoCoVisualFrontend, WhisperConfig, WhisperModel
-from tests.helpers import max_err, seed_module, synthetic_batch, to_device
+from tests.helpers import assert_close, max_err, record, seed_module, synthetic_batch, to_device
 
 pytestmark = pytest.mark.gpu
 
@@ -34,9 +34,9 @@ def test_whisper_encoder(dev, dtype, name):
     ref = oracle.whisper_encoder(sd, "encoder.", mel, cfg.encoder_attention_heads)
     got = m.encoder(mel.to(dev), dtype=dtype)[0]
     assert got.shape == ref.shape
-    assert max_err(got, ref) < TOL[dtype]
+    assert_close(got, ref, TOL[dtype], f"whisper encoder {name} {dtype}")
     got2 = m.encoder(mel.transpose(1, 2).contiguous().to(dev), dtype=dtype, channels_last=True)[0]
-    assert max_err(got2, ref) < TOL[dtype]
+    assert_close(got2, ref, TOL[dtype], f"whisper encoder {name} {dtype} channels-last")
     with pytest.raises(ValueError):
         m.encoder(mel[:, :, :2000].to(dev), dtype=dtype)
 
@@ -194,17 +194,20 @@ def test_fusion_fwd_bwd(dev, dtype):
     ad = a.to(dev, dtype).requires_grad_(True)
     vd = v.to(dev, dtype).requires_grad_(True)
     got = m(ad, vd, None, mask.to(dev))
-    assert max_err(got, ref) < TOL[dtype]
+    assert_close(got, ref, TOL[dtype], f"fusion output {dtype}")
     got.backward(dout.to(dev, dtype))
-    assert max_err(ad.grad, ar.grad) < TOL[dtype] * 2
-    assert max_err(vd.grad, vr.grad) < TOL[dtype] * 2
+    assert_close(ad.grad, ar.grad, TOL[dtype] * 2, f"fusion d/d audio {dtype}")
+    assert_close(vd.grad, vr.grad, TOL[dtype] * 2, f"fusion d/d video {dtype}")
     params = dict(m.named_parameters())
     for k in names:
         assert params[k].grad is not None, k
         # a gate gradient is ONE scalar summed over all B*T*d products dout*y with heavy cancellation (|sum| ~ 8 from
         # terms whose absolute values add up to ~3e4), so bf16 rounding of y shows up amplified: 15 % there
         rel = 0.15 if (k.endswith("_gate") and dtype == torch.bfloat16) else TOL[dtype] * 3
-        assert max_err(params[k].grad, leaf[k].grad) < rel, k
+        if k.endswith("_gate") or leaf[k].grad.numel() < 4096:
+            assert max_err(params[k].grad, leaf[k].grad) < rel, k
+        else:
+            assert_close(params[k].grad, leaf[k].grad, rel, f"fusion grad {k} {dtype}")
 
 
 def _micro_avnet(dtype, dev, vocab=503, p_drop=0.1):
@@ -300,7 +303,7 @@ def test_avnet_forward_and_training_step(dev, dtype):
     vl = bd["video_lengths"].clone()
     logits = m((bd["audio"], bd["audio_mask"], bd["video"], bd["video_mask"], vl))
     assert logits.shape == ref_logits.shape and logits.dtype == torch.float32
-    assert max_err(logits, ref_logits) < TOL[dtype]
+    assert_close(logits, ref_logits, TOL[dtype], f"micro AVNet logits {dtype}")
     ids, ref_ids = m.decode_ids(logits).cpu(), ref_logits.argmax(-1)
     if dtype == torch.float32:
         assert torch.equal(ids, ref_ids)
@@ -308,6 +311,8 @@ def test_avnet_forward_and_training_step(dev, dtype):
         top2 = ref_logits.topk(2, -1).values
         sure = (top2[..., 0] - top2[..., 1]) > 2 * TOL[dtype] * ref_logits.abs().max()
         assert torch.equal(ids[sure], ref_ids[sure])
+        record("micro AVNet bf16 arg-max agreement over all positions", agree=float((ids == ref_ids).float().mean()),
+               positions=ids.numel(), sure_positions=int(sure.sum()))
     # [B,80,3000] input layout gives the same result
     logits2 = m((bd["audio"].transpose(1, 2).contiguous(), bd["audio_mask"], bd["video"], bd["video_mask"],
                  bd["video_lengths"].clone()))
@@ -412,9 +417,9 @@ def test_fusion_vs_reference_golden(dev, dtype):
     ad, vd = a.to(dev, dtype).requires_grad_(True), v.to(dev, dtype).requires_grad_(True)
     y = m(ad, vd, None, mask.to(dev))
     y.backward(dout.to(dev, dtype))
-    assert max_err(y, torch.from_numpy(g["y"])) < TOL[dtype]
-    assert max_err(ad.grad, torch.from_numpy(g["da"])) < TOL[dtype] * 2
-    assert max_err(vd.grad, torch.from_numpy(g["dv"])) < TOL[dtype] * 2
+    assert_close(y, torch.from_numpy(g["y"]), TOL[dtype], f"fusion vs reference-class golden: y {dtype}")
+    assert_close(ad.grad, torch.from_numpy(g["da"]), TOL[dtype] * 2, f"fusion vs reference-class golden: da {dtype}")
+    assert_close(vd.grad, torch.from_numpy(g["dv"]), TOL[dtype] * 2, f"fusion vs reference-class golden: dv {dtype}")
     for k, p in m.named_parameters():
         ref = float(g["gnorm/" + k])
         # scalar gate gradients: cancellation-amplified bf16 rounding, see test_fusion_fwd_bwd
@@ -432,7 +437,7 @@ def test_whisper_vs_transformers_golden(dev, dtype):
     enc.to(dev)
     mel = torch.randn(1, 80, 3000, generator=torch.Generator().manual_seed(3))
     y = enc(mel.to(dev), dtype=dtype)[0]
-    assert max_err(y, torch.from_numpy(g["micro/y"])) < TOL[dtype]
+    assert_close(y, torch.from_numpy(g["micro/y"]), TOL[dtype], f"whisper vs transformers golden {dtype}")
 
 
 def test_head_losses_vs_golden(dev):

@@ -15,7 +15,7 @@ import torch
 
 import oracle
 from mocov2_whisper_flamingo_amd import AVNet, MoCoVisualFrontend, WhisperConfig, WhisperModel
-from tests.helpers import max_err, seed_module, synthetic_batch, to_device
+from tests.helpers import assert_close, closeness, max_err, record, seed_module, synthetic_batch, to_device
 
 pytestmark = pytest.mark.gpu
 
@@ -49,7 +49,7 @@ def test_whisper_encoder_at_benchmark_widths(dev, dtype, name, layers):
     ref = oracle.whisper_encoder(sd, "encoder.", mel, cfg.encoder_attention_heads)
     got = m.encoder(mel.to(dev), dtype=dtype)[0]
     assert got.shape == ref.shape == (1, 1500, full.d_model)
-    assert max_err(got, ref) < TOL[dtype]
+    assert_close(got, ref, TOL[dtype], f"whisper-{name} encoder ({layers} layers) {dtype}")
 
 
 def test_whisper_encoder_batch_8_with_split_attention_rounds(dev):
@@ -97,7 +97,7 @@ def test_visual_frontend_full_clip(dev, dtype, training):
     got = m(video.to(dev), lens.to(dev))
     assert got.shape == ref.shape == (1, 75, 2048)
     assert (got[0, 61:] == 0).all()
-    assert max_err(got, ref) < TOL[dtype] * (2 if training else 1)
+    assert_close(got, ref, TOL[dtype] * (2 if training else 1), f"visual frontend full clip {dtype} training={training}")
     if training:
         now = m.state_dict()
         for k in ("frontend3D.1.running_var", "MoCoModel.layer3.5.bn2.running_mean", "MoCoModel.layer4.2.bn3.running_var"):
@@ -133,15 +133,35 @@ def test_training_step_in_the_benchmark_mode(dev):
         assert (params[k].grad.float().cpu() - gr).abs().max().item() < 5 * tol * scale, k
 
 
-@pytest.mark.parametrize("training", [False, True])
-def test_config2_model_end_to_end(dev, training):
-    """BASELINE.json configuration 2 at its real sizes except the batch (2 clips instead of 8): Whisper-small
+def _replayed_dropout(m, n_blocks, B, H, T, d, p):
+    """The keep masks the device generator draws for the fusion blocks of the model's NEXT training forward."""
+    from tests.philox_ref import attn_keep_mask, keep_mask
+    drop = {"attn": [], "ff": []}
+    for i in range(n_blocks):
+        drop["attn"].append(torch.from_numpy(attn_keep_mask(m._dropout_seed(f"fusion.{i}.attn"), (B, H, T, T), p)))
+        drop["ff"].append(torch.from_numpy(keep_mask(m._dropout_seed(f"fusion.{i}.ff"), (B * T, d), p)).view(B, T, d))
+    return drop
+
+
+def _argmax_agreement(what, m, logits, logits_r, tol):
+    """Greedy ids: asserted equal wherever the reference's top-2 margin exceeds 2 tol max|logit|; the agreement
+    rate over ALL positions is recorded (bf16 ids are not bit-exact near ties)."""
+    ids, ref_ids = m.decode_ids(logits).cpu(), logits_r.argmax(-1)
+    top2 = logits_r.topk(2, -1).values
+    sure = (top2[..., 0] - top2[..., 1]) > 2 * tol * logits_r.abs().max()
+    assert sure.any() and torch.equal(ids[sure], ref_ids[sure])
+    record(what + ": bf16 arg-max agreement over all positions", agree=float((ids == ref_ids).float().mean()),
+           positions=ids.numel(), sure_positions=int(sure.sum()))
+
+
+@pytest.mark.parametrize("training,B", [(False, 8), (True, 2), (True, 8)])
+def test_config2_model_end_to_end(dev, training, B):
+    """BASELINE.json configuration 2 at its real sizes, batch 8 included (the benchmark's tile choices): Whisper-small
     (D 768, 12 layers, 12 heads), 75 frames 96 x 96, fusion width 512 x 8 heads x 3 blocks, vocabulary 51865,
     bf16 compute; eval mode, and the benchmark's train mode (batch-statistics BN + dropout, masks replayed).
     Loss, logits, greedy ids where the reference's top-2 margin exceeds the tolerance, and the gradients of the
     head and of the first fusion block against the oracle."""
     from tests.helpers import MODELARGS
-    from tests.philox_ref import attn_keep_mask, keep_mask
     torch.set_num_threads(16)
     dtype, p, V = torch.bfloat16, 0.1, 51865
     cfg = WhisperConfig.from_name("small", with_decoder=False)
@@ -149,25 +169,18 @@ def test_config2_model_end_to_end(dev, training):
     sd = seed_module(m, 33)
     sd = tame_residual_branches(m.visual_model, sd, "visual_model.")
     m.to(dev).train(training)
-    batch = synthetic_batch(B=2, Tv=75, H=96, W=96, L=32, vocab=V, seed=19)
+    batch = synthetic_batch(B=B, Tv=75, H=96, W=96, L=32, vocab=V, seed=19)
     loss, ctc, ce, logits = m.training_step(to_device(batch, dev))
-    B, T, H, d = 2, 75, 8, 512
-    drop = None
-    if training:
-        drop = {"attn": [], "ff": []}
-        for i in range(3):
-            drop["attn"].append(torch.from_numpy(attn_keep_mask(m._dropout_seed(f"fusion.{i}.attn"), (B, H, T, T), p)))
-            drop["ff"].append(torch.from_numpy(keep_mask(m._dropout_seed(f"fusion.{i}.ff"), (B * T, d), p)).view(B, T, d))
+    T, H, d = 75, 8, 512
+    drop = _replayed_dropout(m, 3, B, H, T, d, p) if training else None
     loss_r, ctc_r, ce_r, logits_r, grads_r, _ = oracle.training_step(sd, batch, 12, 8, training=training, drop=drop,
                                                                      p_drop=p if training else 0.0, masked_row="zero")
     tol = TOL[dtype]
-    assert logits.shape == logits_r.shape == (2, 75, V)
-    assert max_err(logits, logits_r) < tol
+    tag = f"config 2 batch {B} {'train' if training else 'eval'}"
+    assert logits.shape == logits_r.shape == (B, 75, V)
+    assert_close(logits, logits_r, tol, tag + ": logits")
     assert abs(loss.item() - loss_r.item()) < tol * max(1.0, abs(loss_r.item()))
-    ids, ref_ids = m.decode_ids(logits).cpu(), logits_r.argmax(-1)
-    top2 = logits_r.topk(2, -1).values
-    sure = (top2[..., 0] - top2[..., 1]) > 2 * tol * logits_r.abs().max()
-    assert sure.any() and torch.equal(ids[sure], ref_ids[sure])
+    _argmax_agreement(tag, m, logits, logits_r, tol)
     loss.backward()
     params = dict(m.named_parameters())
     for k in ("decoder.linear.weight", "decoder.linear.bias", "fusion_module.layers.0.attn.in_proj_weight",
@@ -175,17 +188,49 @@ def test_config2_model_end_to_end(dev, training):
               "video_proj.weight"):
         gr = grads_r[k]
         assert (params[k].grad.float().cpu() - gr).abs().max().item() < 5 * tol * max(1.0, gr.abs().max().item()), k
+        if gr.numel() >= 4096:
+            c = closeness(params[k].grad, gr, 5 * tol)
+            record(tag + f": gradient {k}", **c)
 
 
-def test_config4_medium_with_noise_augmented_mel(dev):
+def test_config2_untamed_random_trunk_is_reported(dev):
+    """The same end-to-end comparison on the seeded RANDOM trunk (no scaling of the last BN gain): bf16 rounding is
+    amplified block after block by batch-statistics BN on random weights, so no tolerance is asserted here - the
+    error is measured and reported, eval and train mode."""
+    from tests.helpers import MODELARGS
+    torch.set_num_threads(16)
+    dtype, V, B = torch.bfloat16, 51865, 2
+    cfg = WhisperConfig.from_name("small", with_decoder=False)
+    for training in (False, True):
+        m = AVNet("audiovisual", None, 96, (MODELARGS[0], MODELARGS[1], MODELARGS[2], MODELARGS[3], MODELARGS[4], 0.0), V,
+                  whisper_config=cfg, dtype=dtype)
+        sd = seed_module(m, 33)
+        m.to(dev).train(training)
+        batch = synthetic_batch(B=B, Tv=75, H=96, W=96, L=32, vocab=V, seed=19)
+        inp = (batch["audio"], batch["audio_mask"], batch["video"], batch["video_mask"], batch["video_lengths"].clone())
+        ref, parts = oracle.avnet_forward(sd, inp, 12, 8, training=training, new_stats={} if training else None,
+                                          masked_row="zero", return_parts=True)
+        bd = to_device(batch, dev)
+        got = m((bd["audio"], bd["audio_mask"], bd["video"], bd["video_mask"], bd["video_lengths"].clone()))
+        assert torch.isfinite(got).all()
+        vis = m.visual_model(bd["video"], bd["video_lengths"]) if not training else None
+        record(f"config 2 UNTAMED random trunk, {'train' if training else 'eval'} mode (reported, not asserted): logits",
+               **closeness(got, ref, TOL[dtype]))
+        if vis is not None:
+            record("config 2 UNTAMED random trunk, eval mode: visual features", **closeness(vis, parts["visual"], TOL[dtype]))
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_config4_medium_with_noise_augmented_mel(dev, training):
     """BASELINE.json configuration 4 on one clip: the training-time mel pipeline (SpecAugment bands + babble-style
     noise at a drawn SNR + clip layer norm; the noise recording is synthetic, the reference's file is not in the
     checkout) feeding the Whisper-medium AV-net (D 1024, 24 layers, 16 heads) in bf16, against the oracle run on
-    the oracle's own mel of the same waveform and draws.  PARITY UNPINNED for the mel part (torchaudio absent)."""
+    the oracle's own mel of the same waveform and draws; eval mode, and train mode (batch-statistics BN over the one
+    clip's frames, both dropouts replayed).  PARITY UNPINNED for the mel part (torchaudio absent)."""
     from mocov2_whisper_flamingo_amd import LogMelFrontend
     from tests.helpers import MODELARGS
     torch.set_num_threads(16)
-    V = 51865
+    V, p = 51865, 0.1
     g = torch.Generator().manual_seed(41)
     wave = 0.1 * torch.randn(1, 480000, generator=g)
     noise_rec = 0.3 * torch.randn(20000, generator=g)
@@ -196,39 +241,44 @@ def test_config4_medium_with_noise_augmented_mel(dev):
     cfg = WhisperConfig.from_name("medium", with_decoder=False)
     m = AVNet("audiovisual", None, 96, MODELARGS, V, whisper_config=cfg, dtype=torch.bfloat16)
     sd = tame_residual_branches(m.visual_model, seed_module(m, 35), "visual_model.")
-    m.to(dev).eval()
+    m.to(dev).train(training)
     batch = synthetic_batch(B=1, Tv=75, H=96, W=96, L=32, vocab=V, seed=23)
     inp = (mel_ref, batch["audio_mask"], batch["video"], batch["video_mask"], batch["video_lengths"].clone())
-    ref = oracle.avnet_forward(sd, inp, 16, 8, masked_row="zero")
     got = m((mel, batch["audio_mask"].to(dev), batch["video"].to(dev), batch["video_mask"].to(dev),
              batch["video_lengths"].clone().to(dev)))
+    drop = _replayed_dropout(m, 3, 1, 8, 75, 512, p) if training else None
+    ref = oracle.avnet_forward(sd, inp, 16, 8, training=training, new_stats={} if training else None, drop=drop,
+                               p_drop=p if training else 0.0, masked_row="zero")
     assert got.shape == ref.shape == (1, 75, V)
-    assert max_err(got, ref) < TOL[torch.bfloat16]
+    assert_close(got, ref, TOL[torch.bfloat16], f"config 4 one clip {'train' if training else 'eval'}: logits")
 
 
-@pytest.mark.parametrize("attention,tol", [("bf16", 2e-2), ("fp8", 5e-2)])
-def test_config5_large_v2_long_form(dev, attention, tol):
+@pytest.mark.parametrize("attention,tol,training", [("bf16", 2e-2, False), ("fp8", 5e-2, False), ("bf16", 2e-2, True)])
+def test_config5_large_v2_long_form(dev, attention, tol, training):
     """BASELINE.json configuration 5 on one clip: Whisper-large-v2 (D 1280, 32 layers, 20 heads), 60 s of audio
     encoded as two 30 s windows, 150 video frames, bf16 with the encoder's attention products in bf16 or in fp8
-    (e4m3 operands: three mantissa bits, tolerance 5e-2 - proposed here, the task states none for fp8)."""
+    (e4m3 operands: three mantissa bits, tolerance 5e-2 - proposed here, the task states none for fp8); eval mode,
+    and (bf16) train mode with batch-statistics BN and replayed dropout."""
     from tests.helpers import MODELARGS
     torch.set_num_threads(16)
-    V = 51865
+    V, p = 51865, 0.1
     cfg = WhisperConfig.from_name("large-v2", with_decoder=False)
     m = AVNet("audiovisual", None, 96, MODELARGS, V, whisper_config=cfg, dtype=torch.bfloat16, attention=attention,
               long_form=True)
     sd = tame_residual_branches(m.visual_model, seed_module(m, 37), "visual_model.")
-    m.to(dev).eval()
+    m.to(dev).train(training)
     batch = synthetic_batch(B=1, Tv=150, H=96, W=96, L=32, vocab=V, seed=29)
     g = torch.Generator().manual_seed(30)
     audio = torch.randn(1, 6000, 80, generator=g)
     mask = torch.ones(1, 6000, dtype=torch.bool)
     inp = (audio, mask, batch["video"], batch["video_mask"], batch["video_lengths"].clone())
-    ref = oracle.avnet_forward(sd, inp, 20, 8, masked_row="zero", long_form=True)
     got = m((audio.to(dev), mask.to(dev), batch["video"].to(dev), batch["video_mask"].to(dev),
              batch["video_lengths"].clone().to(dev)))
+    drop = _replayed_dropout(m, 3, 1, 8, 150, 512, p) if training else None
+    ref = oracle.avnet_forward(sd, inp, 20, 8, training=training, new_stats={} if training else None, drop=drop,
+                               p_drop=p if training else 0.0, masked_row="zero", long_form=True)
     assert got.shape == ref.shape == (1, 150, V)
-    assert max_err(got, ref) < tol
+    assert_close(got, ref, tol, f"config 5 one clip {attention} attention {'train' if training else 'eval'}: logits")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
