@@ -36,6 +36,7 @@ METRIC = "AV clips/sec (30 s audio+75 video frames) fwd+bwd, Whisper-small"
 MODELARGS = (512, 8, 6, 3000, 2048, 0.1)      # reference config.py:12-17
 VOCAB = 51865
 PEAK_BF16_TFLOPS = 2500.0                      # dense MFMA peak, MI355X
+TRAFFIC_FILE = "r02_pmc_traffic.json"          # HBM counters of the dominant kernel (scripts/pmc_traffic.py)
 
 
 import contextlib
@@ -250,6 +251,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches taken in turn")
     ap.add_argument("--whisper", default="small")
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="train: batch-statistics BN + dropout (what the reference's training_step runs); "
@@ -263,6 +265,9 @@ def main():
                     help="launch the frozen encoders kernel by kernel instead of replaying their HIP graph")
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="launch each bucket's all-reduce from gradient hooks on a side stream during backward")
+    ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="gradient exchange: bucketed all-reduce, or reduce-scatter + AdamW on the owned shard + "
+                         "all-gather of the parameters")
     ap.add_argument("--rehearse-backend", default=None, help="e.g. gloo: rehearse N ranks on fewer GPUs (not a measurement)")
     ap.add_argument("--grad-stream", default="auto", choices=["auto", "on", "off"],
                     help="parameter-gradient kernels on a stream of their own beside the dX chain; auto = only without "
@@ -321,13 +326,20 @@ def main():
     # With the next batch's encoders running beside this batch's tail, the gradient exchange is hidden along with
     # the rest of the tail: it is issued in stream order after backward (two 64 MB-class buckets), not from hooks.
     trainer = FlatTrainer(model, lr=1e-3, bucket_mb=64, overlap=args.overlap_allreduce,
-                          force_collective=bool(args.rehearse_backend), fused_step=True, grad_stream=args.grad_stream == "on" or (args.grad_stream == "auto" and not args.pipeline))
+                          force_collective=bool(args.rehearse_backend), fused_step=True, dp_mode=args.dp_mode, grad_stream=args.grad_stream == "on" or (args.grad_stream == "auto" and not args.pipeline))
     B, T = args.batch, 75 * windows
-    batch = synthetic_batch(B, T, 96, 96, 1234 + rank, dev, mel_frames=3000 * windows)
+    # several distinct synthetic batches, taken in turn: one batch alone (66 MB of video + 7.7 MB of mel) would sit
+    # in the 256 MB Infinity Cache from step to step
+    batches = [synthetic_batch(B, T, 96, 96, 1234 + rank + 1000 * j, dev, mel_frames=3000 * windows)
+               for j in range(max(1, args.batches))]
+    batch = batches[0]
+    taken = [0]
 
     def fresh():
-        b = dict(batch)
-        b["video_lengths"] = batch["video_lengths"].clone()      # forward clamps it in place
+        src = batches[taken[0] % len(batches)]
+        taken[0] += 1
+        b = dict(src)
+        b["video_lengths"] = src["video_lengths"].clone()        # forward clamps it in place
         return b
 
     def step(b=None, encoded=None):
@@ -338,13 +350,16 @@ def main():
         trainer.step()
         return loss
 
-    def run(n):
+    def run(n, marks=None):
         """n complete training steps.  The frozen encoders of batch i+1 are issued (on their own streams) before
         the trainable tail of batch i, so they run beside its small kernels; every batch's encoders, tail,
-        backward, all-reduce and optimizer step are inside the call, the first batch's encoders un-overlapped."""
+        backward, all-reduce and optimizer step are inside the call, the first batch's encoders un-overlapped.
+        ``marks``: a list that receives one event per step, recorded behind the step's optimizer kernels."""
         if not args.pipeline:
             for _ in range(n):
                 loss = step()
+                if marks is not None:
+                    marks.append(torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True)))
             return loss
         cur = fresh()
         enc = model.encode(model.batch_inputs(cur), ahead=True, graph=args.graph)
@@ -354,6 +369,8 @@ def main():
                 nxt = fresh()
                 nenc = model.encode(model.batch_inputs(nxt), ahead=True, graph=args.graph)
             loss = step(cur, enc)
+            if marks is not None:
+                marks.append(torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True)))
             cur, enc = nxt, nenc
         return loss
 
@@ -370,11 +387,19 @@ def main():
         if args.warmup:
             run(args.warmup)
         barrier()
+        marks = []
         t0 = time.perf_counter()
-        loss = run(args.steps)
+        loss = run(args.steps, marks)
         t_issue = time.perf_counter() - t0          # host time to enqueue every step (nothing in run() synchronises)
         barrier()
         dt = time.perf_counter() - t0
+    # steady state: from the end of step 0 to the end of step K-2, every step in between has the next batch's
+    # encoders beside its tail; the rest of `dt` is the pipeline's fill (the first batch's encoders with nothing
+    # beside them) and drain (the last batch's tail alone)
+    steady_ms = fill_drain_ms = None
+    if len(marks) >= 4:
+        steady_ms = marks[0].elapsed_time(marks[-2]) / (len(marks) - 2)
+        fill_drain_ms = dt * 1e3 - steady_ms * args.steps
     if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -402,7 +427,7 @@ def main():
         # blocks launch from C, which the event timing above cannot bracket one by one: traffic_launches says so)
         traffic, traffic_launches = None, None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")) as fh:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", TRAFFIC_FILE)) as fh:
                 rec = json.load(fh)
             traffic, traffic_launches = round(float(rec["hbm_bytes_per_launch"])), int(rec["launches"])
         except (OSError, KeyError, ValueError):
@@ -410,6 +435,9 @@ def main():
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_launches": traffic_launches,
+                    "traffic_source": None if traffic is None else
+                    f"profiles/{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, committed "
+                    "with the code and read back here (not measured by this run)",
                     "kernel": "gemm_bf16_kernel (dense + implicit-GEMM conv instantiations)",
                     "launches_per_step": len(recs), "avg_launch_us": round(tsum / len(recs) * 1e6, 2),
                     "algorithmic_gflop_per_step": round(fsum / 1e9, 1),
@@ -436,7 +464,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_ar = tt.item()
         trainer.flat_grad.zero_()
-        dp_term = {"rccl_ranks": world, "gradient_mb": round(nbytes / 1e6, 1), "buckets": len(trainer.buckets),
+        dp_term = {"rccl_ranks": world, "dp_mode": args.dp_mode, "gradient_mb": round(nbytes / 1e6, 1), "buckets": len(trainer.buckets),
                    "allreduce_ms": round(t_ar * 1e3, 3),
                    "bus_gbps": round(2 * (world - 1) / world * nbytes / t_ar / 1e9, 1), "xgmi_peak_gbps": 7 * 153,
                    "share_of_step": round(t_ar / (dt / args.steps), 3),
@@ -452,13 +480,17 @@ def main():
         out = {
             "metric": METRIC if (args.whisper, args.seconds) == ("small", 30) else
             f"AV clips/sec ({args.seconds} s audio+{T} video frames) fwd+bwd, Whisper-{args.whisper}", "value": round(clips / dt, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step_steady": None if steady_ms is None else round(steady_ms, 3),
+            "fill_drain_ms_per_run": None if fill_drain_ms is None else round(fill_drain_ms, 3),
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Whisper-{args.whisper} + MoCo ResNet-50 frontend + gated xattn, batch {B} x {args.seconds} s "
                                    f"clips ({T} frames 96x96) per GPU, {args.mode}-mode BN/dropout, "
                                    + ("fp8 encoder attention, " if args.attention == "fp8" else "")
                                    + "fwd+bwd+all-reduce+clip+AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
+                       "distinct_batches": len(batches),
                        "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 3)},
             "roofline": roofline, "cpu_baseline": cpu, "roofline_extra": extra, "dp": dp_term,
         }

@@ -16,6 +16,14 @@ Lightning's ``DDPStrategy(find_unused_parameters=True)`` + ``gradient_clip_val``
   runs; xGMI is a point-to-point mesh, so few large messages beat many small ones;
 * clipping needs no extra collective: after the all-reduce every rank holds the
   same averaged gradient and computes the same norm locally.
+
+``dp_mode="rs_ag"`` replaces the all-reduce by its two halves with the optimizer between them: one
+reduce-scatter of the flat gradient buffer (every rank receives the summed gradient of ITS 1/world shard), the
+global norm from one 4-byte all-reduce of the shards' sums of squares, clip + AdamW on the owned shard only
+(the optimizer's read-modify-write pass and both moment buffers shrink by the world size), and one all-gather
+of the updated fp32 parameters.  On the xGMI mesh both halves are direct one-hop exchanges that use all seven
+links of a GPU at once; the bytes on the links equal a ring all-reduce's.  The parameter trajectory is the
+all-reduce mode's (same sums, same optimizer arithmetic; the global norm is summed shard by shard).
 """
 import os
 
@@ -44,7 +52,7 @@ class FlatTrainer:
 
     def __init__(self, model, *, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_grad_norm=1.0,
                  bucket_mb=64, process_group=None, overlap=True, force_collective=False, grad_stream=True, fused_step=False,
-                 accumulate=1):
+                 accumulate=1, dp_mode="allreduce"):
         self.model = model
         self.named = trainable_parameters(model)
         if not self.named:
@@ -58,6 +66,12 @@ class FlatTrainer:
         # force_collective: issue the all-reduces even at world size 1 (a rehearsal of the collective call path)
         self.collective = self.world > 1 or (force_collective and dist.is_available() and dist.is_initialized())
         self.step_count = 0
+        if dp_mode not in ("allreduce", "rs_ag"):
+            raise ValueError('dp_mode must be "allreduce" or "rs_ag"')
+        self.dp_mode = dp_mode
+        self.rank = dist.get_rank(process_group) if self.collective else 0
+        if dp_mode == "rs_ag" and overlap and self.collective:
+            raise ValueError('dp_mode="rs_ag" exchanges the whole buffer after backward: construct with overlap=False')
         # fused_step: the mean over ranks and the next step's zero_grad are folded into the optimizer kernels (one
         # read-modify-write pass and one fill pass over the flat gradient buffer less per step).  Between
         # reduce_gradients() and step() the buffer then holds the SUM over ranks, and after step() it is zero.
@@ -82,10 +96,21 @@ class FlatTrainer:
         for s in sizes:
             offs.append(total)
             total += (s + 3) // 4 * 4
+        self.used = total
+        self.shard = None
+        if dp_mode == "rs_ag":
+            # equal shards of whole 16-byte groups; the padding at the end of the buffer stays zero
+            parts = self.world if self.collective else 1
+            per = (total + 4 * parts - 1) // (4 * parts) * 4
+            total = per * parts
+            self.shard = (self.rank * per, (self.rank + 1) * per)
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        # rs_ag: the optimizer state exists for the owned shard only; the reduce-scatter lands in a buffer of its own
+        n_state = total if self.shard is None else self.shard[1] - self.shard[0]
+        self.exp_avg = torch.zeros(n_state, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n_state, dtype=torch.float32, device=dev)
+        self.grad_shard = torch.zeros(n_state, dtype=torch.float32, device=dev) if self.shard is not None else None
         self.slices = {}
         with torch.no_grad():
             for (n, p), o, s in zip(order, offs, sizes):
@@ -221,6 +246,9 @@ class FlatTrainer:
         """Finish the all-reduce of every bucket (launching those the hooks did not) and
         turn the sums into means."""
         self.join_gradients()
+        if self.shard is not None:
+            self._reduce_scatter()
+            return
         if not self.collective:
             return
         if not self.overlap:
@@ -249,11 +277,39 @@ class FlatTrainer:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._to_mean()
 
+    def _reduce_scatter(self):
+        """rs_ag: the summed gradient of this rank's shard -> ``grad_shard`` (one collective over the whole buffer)."""
+        lo, hi = self.shard
+        if not self.collective:
+            self.grad_shard.copy_(self.flat_grad[lo:hi])
+        elif self._gloo_on_gpu() and not GLOO_DEVICE_TENSORS:      # see _reduce_bucket: host copies on a shared GPU
+            host, out = self.flat_grad.cpu(), torch.empty(hi - lo)
+            dist.reduce_scatter_tensor(out, host, op=dist.ReduceOp.SUM, group=self.group)
+            self.grad_shard.copy_(out)
+        else:
+            dist.reduce_scatter_tensor(self.grad_shard, self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        self._to_mean()
+
+    def _all_gather_params(self):
+        """rs_ag: every rank's updated shard -> the whole flat parameter buffer on every rank."""
+        if not self.collective:
+            return
+        lo, hi = self.shard
+        if self._gloo_on_gpu() and not GLOO_DEVICE_TENSORS:
+            host = torch.empty(self.flat_param.numel())
+            dist.all_gather_into_tensor(host, self.flat_param[lo:hi].cpu(), group=self.group)
+            self.flat_param.copy_(host)
+        else:
+            mine = self.flat_param[lo:hi]
+            if dist.get_backend(self.group) != "nccl":
+                mine = mine.clone()           # RCCL gathers in place (input = output + rank * count); others get a copy
+            dist.all_gather_into_tensor(self.flat_param, mine, group=self.group)
+
     def _to_mean(self):
         if self.fused_step:
             self._pre_scale = 1.0 / self.world       # applied by the clip / AdamW kernels
         elif self.world > 1:
-            self.flat_grad.mul_(1.0 / self.world)
+            (self.flat_grad if self.shard is None else self.grad_shard).mul_(1.0 / self.world)
 
     def join_gradients(self):
         """Make the current stream wait for the parameter-gradient kernels queued on ``grad_stream``."""
@@ -268,13 +324,30 @@ class FlatTrainer:
         lr = self.lr if lr is None else lr
         scr = self._scratch
         scr.zero_()
-        ops.sumsq_accumulate(self.flat_grad, scr[0:1])
-        ops.clip_scale(scr[0:1], self.max_norm, scr[1:2], scr[2:3], pre_scale=self._pre_scale)
-        ops.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, lr=lr,
-                       betas=self.betas, eps=self.eps, weight_decay=self.wd, grad_scale=scr[1:2],
-                       clear_grad=self.fused_step)
+        if self.shard is None:
+            ops.sumsq_accumulate(self.flat_grad, scr[0:1])
+            ops.clip_scale(scr[0:1], self.max_norm, scr[1:2], scr[2:3], pre_scale=self._pre_scale)
+            ops.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, lr=lr,
+                           betas=self.betas, eps=self.eps, weight_decay=self.wd, grad_scale=scr[1:2],
+                           clear_grad=self.fused_step)
+            self._clean = self.fused_step
+        else:
+            # the norm of the whole gradient = the shards' sums of squares added up (4 bytes over the links)
+            lo, hi = self.shard
+            ops.sumsq_accumulate(self.grad_shard, scr[0:1])
+            if self.collective:
+                if self._gloo_on_gpu() and not GLOO_DEVICE_TENSORS:
+                    host = scr[0:1].cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                    scr[0:1].copy_(host)
+                else:
+                    dist.all_reduce(scr[0:1], op=dist.ReduceOp.SUM, group=self.group)
+            ops.clip_scale(scr[0:1], self.max_norm, scr[1:2], scr[2:3], pre_scale=self._pre_scale)
+            ops.adamw_step(self.flat_param[lo:hi], self.grad_shard, self.exp_avg, self.exp_avg_sq, self.step_count, lr=lr,
+                           betas=self.betas, eps=self.eps, weight_decay=self.wd, grad_scale=scr[1:2])
+            self._all_gather_params()
+            self._clean = False               # the flat gradient buffer still holds this step's local gradients
         self._pre_scale = 1.0
-        self._clean = self.fused_step
         # parameters changed in place behind torch's back: drop the compute-dtype weight copies
         cache = getattr(self.model, "_cache", None)
         if cache is not None:

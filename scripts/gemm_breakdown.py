@@ -27,6 +27,11 @@ def step():
 
 for _ in range(3):
     step()
+# per-launch durations of the kernel alone: nothing on a second stream sharing the CUs
+from mocov2_whisper_flamingo_amd import functional as Fn
+model.overlap_encoders = False
+Fn.GRAD_STREAM = None
+step()
 ops.GEMM_PROFILE = []
 ops.GEMM_PROFILE_REPEAT = '--repeat' in sys.argv
 step()

@@ -209,6 +209,97 @@ def test_dp_gradient_accumulation_over_gloo(overlap):
     assert nb > 1
 
 
+def _cpu_optimizer_ops(monkeypatch_target):
+    """Plain-torch stand-ins for the three optimizer kernels (same arithmetic as csrc/elementwise.hip), so the
+    host logic of FlatTrainer.step() - sharding, collectives, buffer bookkeeping - can run on CPU tensors."""
+    import math
+
+    def sumsq_accumulate(x, out):
+        out += x.double().pow(2).sum().float()
+
+    def clip_scale(sumsq, max_norm, scale, norm_out=None, pre_scale=1.0):
+        nrm = pre_scale * math.sqrt(float(sumsq[0]))
+        if norm_out is not None:
+            norm_out[0] = nrm
+        scale[0] = pre_scale * min(1.0, max_norm / (nrm + 1e-6))
+
+    def adamw_step(param, grad, exp_avg, exp_avg_sq, step, *, lr, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01,
+                   grad_scale=None, bf16_shadow=None, clear_grad=False):
+        g = grad * (grad_scale[0] if grad_scale is not None else 1.0)
+        if clear_grad:
+            grad.zero_()
+        bc1, bc2 = 1.0 - betas[0] ** step, 1.0 - betas[1] ** step
+        param.mul_(1.0 - lr * weight_decay)
+        exp_avg.mul_(betas[0]).add_(g, alpha=1.0 - betas[0])
+        exp_avg_sq.mul_(betas[1]).addcmul_(g, g, value=1.0 - betas[1])
+        param.addcdiv_(exp_avg, exp_avg_sq.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
+
+    monkeypatch_target.sumsq_accumulate, monkeypatch_target.clip_scale = sumsq_accumulate, clip_scale
+    monkeypatch_target.adamw_step = adamw_step
+
+
+def _rs_ag_worker(rank, world, port, q, fused):
+    """Three optimizer steps with known per-rank gradients, once with the bucketed all-reduce and once with
+    reduce-scatter + sharded AdamW + all-gather: the same parameters after every step, on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        from mocov2_whisper_flamingo_amd import ops
+        _cpu_optimizer_ops(ops)
+        ma, _ = micro_model()
+        mb, _ = micro_model()
+        ta = FlatTrainer(ma, bucket_mb=0.25, overlap=False, fused_step=fused, lr=1e-2, max_grad_norm=0.5)
+        tb = FlatTrainer(mb, overlap=False, fused_step=fused, lr=1e-2, max_grad_norm=0.5, dp_mode="rs_ag")
+        assert tb.flat_param.numel() % (4 * world) == 0 and tb.exp_avg.numel() * world == tb.flat_param.numel()
+        assert tb.exp_avg.numel() < ta.exp_avg.numel()                   # optimizer state for the owned shard only
+        worst = 0.0
+        for step in range(3):
+            for tr in (ta, tb):
+                tr.zero_grad()
+                g = torch.Generator().manual_seed(100 * step + rank)
+                with torch.no_grad():
+                    for _, p in tr.named:
+                        p.grad.add_(torch.randn(p.shape, generator=g) * (0.1 + step))    # some steps clip, some do not
+                tr.reduce_gradients()
+                tr.step()
+            for (na, pa), (nb, pb) in zip(ta.named, tb.named):
+                assert na == nb
+                worst = max(worst, ((pa - pb).abs().max() / pa.abs().max().clamp_min(1e-6)).item())
+            assert abs(ta.grad_norm().item() - tb.grad_norm().item()) <= 1e-5 * ta.grad_norm().item()
+            # every rank holds the same parameters after the all-gather
+            mine = tb.flat_param.clone()
+            dist.broadcast(mine, src=0)
+            assert torch.equal(mine, tb.flat_param)
+        if rank == 0:
+            q.put(("ok", worst))
+        dist.barrier()
+    except Exception as e:
+        if rank == 0:
+            q.put(("error", repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fused", [(2, False), (2, True), (4, True)])
+def test_dp_reduce_scatter_all_gather_mode_follows_the_all_reduce_trajectory(world, fused):
+    """FlatTrainer(dp_mode="rs_ag") (train.py:312-326 as reduce-scatter + AdamW on the owned shard + all-gather)
+    against the all-reduce mode over three steps, world size 2 and 4 on gloo."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rs_ag_worker, args=(r, world, port, q, fused)) for r in range(world)]
+    for p in procs:
+        p.start()
+    status, worst = q.get(timeout=300)
+    for p in procs:
+        p.join(60)
+    assert status == "ok", worst
+    assert all(p.exitcode == 0 for p in procs)
+    assert worst < 1e-5
+
+
 def test_adaptive_time_mask_draws_like_the_reference():
     """Host-side draw of AdaptiveTimeMask (datamodule/transforms.py:27-45): one candidate per started 25 frames,
     mask lengths below the window, nothing outside the clip; a zero first draw skips the mask after its start
