@@ -272,6 +272,8 @@ def main():
     ap.add_argument("--grad-stream", default="auto", choices=["auto", "on", "off"],
                     help="parameter-gradient kernels on a stream of their own beside the dX chain; auto = only without "
                          "the pipeline (with it, the step time then hinges on which hardware queue that stream lands on)")
+    ap.add_argument("--no-tail-graph", dest="tail_graph", action="store_false",
+                    help="enqueue the trainable tail kernel by kernel instead of replaying its two HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-roofline-extra", action="store_true", help="skip the per-kernel rooflines beside the GEMM's")
@@ -342,7 +344,14 @@ def main():
         b["video_lengths"] = src["video_lengths"].clone()        # forward clamps it in place
         return b
 
+    from mocov2_whisper_flamingo_amd.dp import GraphedTail
+    use_tail_graph = (args.tail_graph and args.pipeline and args.dp_mode == "allreduce" and not args.overlap_allreduce
+                      and trainer.grad_stream is None)
+    tail_graph = GraphedTail(trainer, warmup=2) if use_tail_graph else None
+
     def step(b=None, encoded=None):
+        if tail_graph is not None and encoded is not None:
+            return tail_graph.step(b, encoded)[0]
         trainer.zero_grad()
         loss, ctc, ce, _ = model.training_step(b or fresh(), encoded=encoded)
         loss.backward()
@@ -491,6 +500,8 @@ def main():
                                    + "fwd+bwd+all-reduce+clip+AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
                        "distinct_batches": len(batches),
+                       "tail": "two HIP graphs (forward+backward, clip+AdamW+weight refresh)"
+                       if (tail_graph is not None and tail_graph.rec is not None) else "eager launches",
                        "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 3)},
             "roofline": roofline, "cpu_baseline": cpu, "roofline_extra": extra, "dp": dp_term,
         }

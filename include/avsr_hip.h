@@ -93,6 +93,9 @@ typedef struct {
     const void* mul_gelu_grad_of; int64_t ld_aux;
     float p_drop;
     uint64_t seed;
+    /* optional device word added to `seed` when the kernel runs (NULL = none): lets a launch recorded in a HIP
+     * graph draw a different dropout mask on every replay (see avsr_step_params) */
+    const uint64_t* seed_delta;
 } avsr_gemm_t;
 
 int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g);
@@ -201,6 +204,7 @@ typedef struct {
     int64_t B, Tq, Tk, d, H, d_ff;
     float p_drop;                    /* 0 in eval mode */
     uint64_t seed_attn, seed_ff;
+    const uint64_t* seed_delta;      /* optional device word added to both seeds at run time (NULL = none): graph replays */
     const void* w_in;  const void* w_inT;  int64_t ld_inT;  const float* b_in;    /* attn.in_proj_weight [3d, d], ^T [d, ld] */
     const void* w_out; const void* w_outT; int64_t ld_outT; const float* b_out;   /* attn.out_proj       [d, d]            */
     const void* w_fc1; const void* w_fc1T; int64_t ld_fc1T; const float* b_fc1;   /* ff.0                [d_ff, d]         */
@@ -431,6 +435,20 @@ int avsr_clip_scale(avsr_stream_t stream, const float* sumsq, float max_norm, fl
 int avsr_adamw_step(avsr_stream_t stream, float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                     void* bf16_shadow, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int64_t step, const float* grad_scale, int clear_grad);
+/* The per-step scalars of a training step that is replayed from a HIP graph (train.py:218-246: the OneCycleLR
+ * learning rate and AdamW's step count change every step, and so must every dropout mask): one launch, outside the
+ * graph, writes them into a 32-byte device record the recorded kernels read -
+ *   +0  uint64  seed_delta   (what avsr_gemm_t.seed_delta / avsr_xattn_block_t.seed_delta point at)
+ *   +8  float   lr, +12 float 1 - beta1^step, +16 float 1 - beta2^step   (what avsr_adamw_step_dev reads).
+ * The values travel as kernel arguments, so the host may run any number of steps ahead of the GPU.
+ * avsr_adamw_step_dev is avsr_adamw_step with lr and the two bias corrections taken from `hyper` = record + 8;
+ * clip_scale_reset != NULL: the word it points at (the sum of squares the clip factor was computed from) is set
+ * to zero afterwards, ready for the next step's avsr_sumsq_accumulate. */
+int avsr_step_params(avsr_stream_t stream, void* record, uint64_t seed_delta, float lr, float beta1, float beta2,
+                     int64_t step);
+int avsr_adamw_step_dev(avsr_stream_t stream, float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                        void* bf16_shadow, int64_t n, const float* hyper, float beta1, float beta2, float eps,
+                        float weight_decay, const float* grad_scale, int clear_grad, float* clip_scale_reset);
 
 #ifdef __cplusplus
 }

@@ -30,13 +30,14 @@ class GemmDesc(_c.Structure):
         ("residual", _vp), ("ldr", _i64), ("res_period", _i64), ("gate", _vp),
         ("col_sum", _vp), ("col_sumsq", _vp), ("conv", ConvDesc),
         ("pre", _vp), ("ldp", _i64), ("mul_gelu_grad_of", _vp), ("ld_aux", _i64), ("p_drop", _f32), ("seed", _u64),
+        ("seed_delta", _vp),
     ]
 
 
 class XattnBlock(_c.Structure):
     _fields_ = [
         ("dtype", _i32), ("B", _i64), ("Tq", _i64), ("Tk", _i64), ("d", _i64), ("H", _i64), ("d_ff", _i64),
-        ("p_drop", _f32), ("seed_attn", _u64), ("seed_ff", _u64),
+        ("p_drop", _f32), ("seed_attn", _u64), ("seed_ff", _u64), ("seed_delta", _vp),
         ("w_in", _vp), ("w_inT", _vp), ("ld_inT", _i64), ("b_in", _vp),
         ("w_out", _vp), ("w_outT", _vp), ("ld_outT", _i64), ("b_out", _vp),
         ("w_fc1", _vp), ("w_fc1T", _vp), ("ld_fc1T", _i64), ("b_fc1", _vp),
@@ -114,6 +115,8 @@ SIGNATURES = {
     "avsr_sumsq_accumulate": (_i32, [_vp, _vp, _i64, _vp]),
     "avsr_clip_scale": (_i32, [_vp, _vp, _f32, _f32, _vp, _vp]),
     "avsr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _vp, _i32]),
+    "avsr_step_params": (_i32, [_vp, _vp, _u64, _f32, _f32, _f32, _i64]),
+    "avsr_adamw_step_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
 }
 
 _lib = None

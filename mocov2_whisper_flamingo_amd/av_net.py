@@ -86,14 +86,17 @@ class AVNet(nn.Module):
         self._side = None
         self._aside = None
         self._graphs = {}
-        self.fusion_module.set_runtime(self._cache, self._dropout_seed)
+        self._seed_delta = None             # device record of a graphed training step (dp.GraphedTail), else None
+        self.fusion_module.set_runtime(self._cache, self._dropout_seed, lambda: self._seed_delta)
         if device is not None:
             self.to(device)
 
     # ---- runtime helpers --------------------------------------------------
+    SEED_STEP_MUL = 0xBF58476D1CE4E5B9      # a step further = this much more on every site's seed (mod 2^64)
+
     def _dropout_seed(self, tag):
         """A distinct 64-bit stream id per (construction seed, forward call, site)."""
-        mix = self._seed * 0x9E3779B97F4A7C15 + self._step * 0xBF58476D1CE4E5B9 + zlib.crc32(tag.encode())
+        mix = self._seed * 0x9E3779B97F4A7C15 + self._step * self.SEED_STEP_MUL + zlib.crc32(tag.encode())
         return mix & 0xFFFFFFFFFFFFFFFF
 
     @property
@@ -248,8 +251,9 @@ class AVNet(nn.Module):
         enc, vis = encoded["enc"], encoded["vis"]
         for stream, ev in encoded["done"]:
             main.wait_event(ev)
-        for tns in (enc, vis):
-            tns.record_stream(main)
+        if not torch.cuda.is_current_stream_capturing():
+            for tns in (enc, vis):
+                tns.record_stream(main)
         ready = getattr(self, "_weights_ready", None)     # compute-dtype weight copies rebuilt on another stream
         if ready is not None:
             main.wait_event(ready)

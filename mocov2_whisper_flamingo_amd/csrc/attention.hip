@@ -91,9 +91,10 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
                                                             long ldk, const bf16_t* __restrict__ V, long ldv,
                                                             bf16_t* __restrict__ O, long ldo, const uint8_t* __restrict__ mask,
                                                             float* __restrict__ lse, int Tq, int Tk, int H, float scale,
-                                                            float pdrop, uint64_t seed, int B, int causal,
+                                                            float pdrop, uint64_t seed_in, const uint64_t* __restrict__ seed_delta, int B, int causal,
                                                             int whole_per_xcd, int nsplit, float* __restrict__ part_ws,
                                                             int* __restrict__ tickets) {
+    const uint64_t seed = avsr_run_seed(seed_in, seed_delta);   // by-value seed + the optional device word
     __shared__ __attribute__((aligned(16))) bf16_t Kbuf[ATT_NBUF][64 * 64];      // ring: one barrier per key tile
     __shared__ __attribute__((aligned(16))) bf16_t Vbuf[ATT_NBUF][64 * 64];
     __shared__ int last_part;
@@ -656,7 +657,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(
     const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K, long ldk, const bf16_t* __restrict__ V, long ldv,
     const bf16_t* __restrict__ O, long ldo, const bf16_t* __restrict__ dO, long lddo, bf16_t* __restrict__ dQ, long lddq,
     const uint8_t* __restrict__ mask, const float* __restrict__ lse, float* __restrict__ Dout, int Tq, int Tk, int H,
-    float scale, float pdrop, uint64_t seed) {
+    float scale, float pdrop, uint64_t seed_in, const uint64_t* __restrict__ seed_delta) {
+    const uint64_t seed = avsr_run_seed(seed_in, seed_delta);   // by-value seed + the optional device word
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * 64];
     __shared__ __attribute__((aligned(16))) bf16_t Kt[64 * 64];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * 64];
@@ -770,7 +772,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(
     const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K, long ldk, const bf16_t* __restrict__ V, long ldv,
     const bf16_t* __restrict__ dO, long lddo, bf16_t* __restrict__ dK, long lddk, bf16_t* __restrict__ dV, long lddv,
     const uint8_t* __restrict__ mask, const float* __restrict__ lse, const float* __restrict__ Dsum, int Tq, int Tk, int H,
-    float scale, float pdrop, uint64_t seed) {
+    float scale, float pdrop, uint64_t seed_in, const uint64_t* __restrict__ seed_delta) {
+    const uint64_t seed = avsr_run_seed(seed_in, seed_delta);   // by-value seed + the optional device word
     __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * 64];
     __shared__ __attribute__((aligned(16))) bf16_t Qt[64 * 64];
     __shared__ __attribute__((aligned(16))) bf16_t Os[64 * 64];
@@ -897,8 +900,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_valu_kernel(const T* __restrict__ Q, long ldq, const T* __restrict__ K, long ldk,
                                                             const T* __restrict__ V, long ldv, T* __restrict__ O, long ldo,
                                                             const uint8_t* __restrict__ mask, float* __restrict__ lse,
-                                                            int Tq, int Tk, int H, float scale, float pdrop, uint64_t seed,
+                                                            int Tq, int Tk, int H, float scale, float pdrop, uint64_t seed_in, const uint64_t* __restrict__ seed_delta,
                                                             int causal) {
+    const uint64_t seed = avsr_run_seed(seed_in, seed_delta);   // by-value seed + the optional device word
     __shared__ float Ks[64 * KLD], Vs[64 * KLD], Qs[32 * KLD];
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -959,7 +963,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_valu_kernel(const T* __restri
                                                                const T* __restrict__ dO, long lddo, T* __restrict__ dQ, long lddq,
                                                                const uint8_t* __restrict__ mask, const float* __restrict__ lse,
                                                                float* __restrict__ Dout, int Tq, int Tk, int H, float scale,
-                                                               float pdrop, uint64_t seed) {
+                                                               float pdrop, uint64_t seed_in, const uint64_t* __restrict__ seed_delta) {
+    const uint64_t seed = avsr_run_seed(seed_in, seed_delta);   // by-value seed + the optional device word
     __shared__ float Ks[64 * KLD], Vs[64 * KLD], Qs[32 * KLD], dOs[32 * KLD];
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1022,7 +1027,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_valu_kernel(const T* __restr
                                                                 T* __restrict__ dK, long lddk, T* __restrict__ dV, long lddv,
                                                                 const uint8_t* __restrict__ mask, const float* __restrict__ lse,
                                                                 const float* __restrict__ Dsum, int Tq, int Tk, int H, float scale,
-                                                                float pdrop, uint64_t seed) {
+                                                                float pdrop, uint64_t seed_in, const uint64_t* __restrict__ seed_delta) {
+    const uint64_t seed = avsr_run_seed(seed_in, seed_delta);   // by-value seed + the optional device word
     __shared__ float Ks[64 * KLD], Vs[64 * KLD], Qs[32 * KLD], dOs[32 * KLD];
     const int b = blockIdx.z, h = blockIdx.y, kv0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1134,10 +1140,11 @@ extern "C" int64_t avsr_attn_fwd_workspace_bytes(int64_t B, int64_t H, int64_t T
     return ((nitems * 4 + 255) / 256) * 256 + nitems * pl.nsplit * 4 * 34 * 64 * 4;
 }
 
-extern "C" int avsr_attn_fwd_ws(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
+extern "C" int avsr_attn_fwd_sd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
                                 int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
                                 float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
-                                float p_drop, uint64_t seed, int causal, void* workspace, int64_t workspace_bytes) {
+                                float p_drop, uint64_t seed, const uint64_t* seed_delta, int causal, void* workspace,
+                                int64_t workspace_bytes) {
     if (!Q || !K || !V || !O || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return AVSR_EINVAL;
     if (causal && Tk < Tq) return AVSR_EINVAL;
     if (use_mfma < 0 || use_mfma > 2) return AVSR_EINVAL;
@@ -1175,17 +1182,17 @@ extern "C" int avsr_attn_fwd_ws(avsr_stream_t stream, int dtype, int use_mfma, c
         if (p_drop > 0.f)
             hipLaunchKernelGGL((attn_fwd_mfma_kernel<true, false>), grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                                (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
-                               (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, (int)B, causal, pl.whole, pl.nsplit, part_ws,
+                               (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, seed_delta, (int)B, causal, pl.whole, pl.nsplit, part_ws,
                                tickets);
         else if (!key_mask && !causal)                          // the software-pipelined form
             hipLaunchKernelGGL((attn_fwd_mfma_kernel<false, true>), grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                                (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
-                               (int)Tq, (int)Tk, (int)H, scale, 0.f, seed, (int)B, causal, pl.whole, pl.nsplit, part_ws,
+                               (int)Tq, (int)Tk, (int)H, scale, 0.f, seed, seed_delta, (int)B, causal, pl.whole, pl.nsplit, part_ws,
                                tickets);
         else
             hipLaunchKernelGGL((attn_fwd_mfma_kernel<false, false>), grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                                (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
-                               (int)Tq, (int)Tk, (int)H, scale, 0.f, seed, (int)B, causal, pl.whole, pl.nsplit, part_ws,
+                               (int)Tq, (int)Tk, (int)H, scale, 0.f, seed, seed_delta, (int)B, causal, pl.whole, pl.nsplit, part_ws,
                                tickets);
         return avsr_launch_status();
     }
@@ -1193,28 +1200,37 @@ extern "C" int avsr_attn_fwd_ws(avsr_stream_t stream, int dtype, int use_mfma, c
     if (dtype == AVSR_F32)
         hipLaunchKernelGGL(attn_fwd_valu_kernel<float>, grid, dim3(256), 0, s, (const float*)Q, (long)ldq, (const float*)K,
                            (long)ldk, (const float*)V, (long)ldv, (float*)O, (long)ldo, key_mask, lse, (int)Tq, (int)Tk,
-                           (int)H, scale, p_drop, seed, causal);
+                           (int)H, scale, p_drop, seed, seed_delta, causal);
     else if (dtype == AVSR_BF16)
         hipLaunchKernelGGL(attn_fwd_valu_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq,
                            (const bf16_t*)K, (long)ldk, (const bf16_t*)V, (long)ldv, (bf16_t*)O, (long)ldo, key_mask, lse,
-                           (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, causal);
+                           (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, seed_delta, causal);
     else return AVSR_EINVAL;
     return avsr_launch_status();
+}
+
+extern "C" int avsr_attn_fwd_ws(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
+                                int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
+                                float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
+                                float p_drop, uint64_t seed, int causal, void* workspace, int64_t workspace_bytes) {
+    return avsr_attn_fwd_sd(stream, dtype, use_mfma, Q, ldq, K, ldk, V, ldv, O, ldo, key_mask, lse, B, H, Tq, Tk, head_dim,
+                            scale, p_drop, seed, nullptr, causal, workspace, workspace_bytes);
 }
 
 extern "C" int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
                              int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
                              float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
                              float p_drop, uint64_t seed, int causal) {
-    return avsr_attn_fwd_ws(stream, dtype, use_mfma, Q, ldq, K, ldk, V, ldv, O, ldo, key_mask, lse, B, H, Tq, Tk, head_dim,
-                            scale, p_drop, seed, causal, nullptr, 0);
+    return avsr_attn_fwd_sd(stream, dtype, use_mfma, Q, ldq, K, ldk, V, ldv, O, ldo, key_mask, lse, B, H, Tq, Tk, head_dim,
+                            scale, p_drop, seed, nullptr, causal, nullptr, 0);
 }
 
-extern "C" int avsr_attn_bwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K, int64_t ldk,
-                             const void* V, int64_t ldv, const void* O, int64_t ldo, const void* dO, int64_t lddo,
-                             void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv,
-                             const uint8_t* key_mask, const float* lse, float* d_ws, int64_t B, int64_t H, int64_t Tq,
-                             int64_t Tk, int64_t head_dim, float scale, float p_drop, uint64_t seed) {
+extern "C" int avsr_attn_bwd_sd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K, int64_t ldk,
+                                const void* V, int64_t ldv, const void* O, int64_t ldo, const void* dO, int64_t lddo,
+                                void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv,
+                                const uint8_t* key_mask, const float* lse, float* d_ws, int64_t B, int64_t H, int64_t Tq,
+                                int64_t Tk, int64_t head_dim, float scale, float p_drop, uint64_t seed,
+                                const uint64_t* seed_delta) {
     if (!Q || !K || !V || !O || !dO || !dQ || !dK || !dV || !lse || !d_ws) return AVSR_EINVAL;
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return AVSR_EINVAL;
     if (head_dim != HD || B > 65535 || H > 65535) return AVSR_EUNSUPPORTED;
@@ -1230,10 +1246,10 @@ extern "C" int avsr_attn_bwd(avsr_stream_t stream, int dtype, int use_mfma, cons
 #define RUN_MFMA(DROP)                                                                                                   \
     hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<DROP>, g1, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq, (const bf16_t*)K, \
                        (long)ldk, (const bf16_t*)V, (long)ldv, (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, \
-                       (bf16_t*)dQ, (long)lddq, key_mask, lse, d_ws, (int)Tq, (int)Tk, (int)H, scale, p_drop, seed);        \
+                       (bf16_t*)dQ, (long)lddq, key_mask, lse, d_ws, (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, seed_delta); \
     hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<DROP>, g2, dim3(256), 0, s, (const bf16_t*)Q, (long)ldq, (const bf16_t*)K, \
                        (long)ldk, (const bf16_t*)V, (long)ldv, (const bf16_t*)dO, (long)lddo, (bf16_t*)dK, (long)lddk,       \
-                       (bf16_t*)dV, (long)lddv, key_mask, lse, d_ws, (int)Tq, (int)Tk, (int)H, scale, p_drop, seed)
+                       (bf16_t*)dV, (long)lddv, key_mask, lse, d_ws, (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, seed_delta)
         if (p_drop > 0.f) { RUN_MFMA(true); } else { RUN_MFMA(false); }
 #undef RUN_MFMA
         return avsr_launch_status();
@@ -1242,15 +1258,24 @@ extern "C" int avsr_attn_bwd(avsr_stream_t stream, int dtype, int use_mfma, cons
 #define RUN(T)                                                                                                          \
     hipLaunchKernelGGL(attn_bwd_dq_valu_kernel<T>, gq, dim3(256), 0, s, (const T*)Q, (long)ldq, (const T*)K, (long)ldk, \
                        (const T*)V, (long)ldv, (const T*)O, (long)ldo, (const T*)dO, (long)lddo, (T*)dQ, (long)lddq,    \
-                       key_mask, lse, d_ws, (int)Tq, (int)Tk, (int)H, scale, p_drop, seed);                             \
+                       key_mask, lse, d_ws, (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, seed_delta);                 \
     hipLaunchKernelGGL(attn_bwd_dkv_valu_kernel<T>, gk, dim3(256), 0, s, (const T*)Q, (long)ldq, (const T*)K, (long)ldk,\
                        (const T*)V, (long)ldv, (const T*)dO, (long)lddo, (T*)dK, (long)lddk, (T*)dV, (long)lddv,        \
-                       key_mask, lse, d_ws, (int)Tq, (int)Tk, (int)H, scale, p_drop, seed)
+                       key_mask, lse, d_ws, (int)Tq, (int)Tk, (int)H, scale, p_drop, seed, seed_delta)
     if (dtype == AVSR_F32) { RUN(float); }
     else if (dtype == AVSR_BF16) { RUN(bf16_t); }
     else return AVSR_EINVAL;
 #undef RUN
     return avsr_launch_status();
+}
+
+extern "C" int avsr_attn_bwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K, int64_t ldk,
+                             const void* V, int64_t ldv, const void* O, int64_t ldo, const void* dO, int64_t lddo,
+                             void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv,
+                             const uint8_t* key_mask, const float* lse, float* d_ws, int64_t B, int64_t H, int64_t Tq,
+                             int64_t Tk, int64_t head_dim, float scale, float p_drop, uint64_t seed) {
+    return avsr_attn_bwd_sd(stream, dtype, use_mfma, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv,
+                            key_mask, lse, d_ws, B, H, Tq, Tk, head_dim, scale, p_drop, seed, nullptr);
 }
 
 // Debugging aid: resident workgroups per CU the runtime computes for the forward kernels (registers + LDS).

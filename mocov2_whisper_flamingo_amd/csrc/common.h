@@ -200,6 +200,27 @@ __host__ __device__ __forceinline__ bool avsr_attn_keep(uint64_t seed, uint64_t 
     return avsr_bits_keep(o[key & 3], p);
 }
 
+// Internal entry points shared between the source files (exported, but not part of the declared interface): the
+// public forms with one more argument, a device word that is added to the dropout seed when the kernel runs.
+extern "C" int avsr_attn_fwd_sd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
+                                int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, const uint8_t* key_mask,
+                                float* lse, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
+                                float p_drop, uint64_t seed, const uint64_t* seed_delta, int causal, void* workspace,
+                                int64_t workspace_bytes);
+extern "C" int avsr_attn_bwd_sd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,
+                                int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo, const void* dO,
+                                int64_t lddo, void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv,
+                                const uint8_t* key_mask, const float* lse, float* d_ws, int64_t B, int64_t H, int64_t Tq,
+                                int64_t Tk, int64_t head_dim, float scale, float p_drop, uint64_t seed,
+                                const uint64_t* seed_delta);
+extern "C" int avsr_gated_residual_bwd_sd(avsr_stream_t stream, int dtype, const void* dout, const void* y, const float* gate,
+                                          void* dy, float* dgate, int64_t n, float p_drop, uint64_t seed,
+                                          const uint64_t* seed_delta);
+// the seed a kernel uses: the by-value seed plus the optional device word (one uniform load)
+__device__ __forceinline__ uint64_t avsr_run_seed(uint64_t seed, const uint64_t* delta) {
+    return delta ? seed + *delta : seed;
+}
+
 // ------------------------------------------------------------ LDS-DMA ----
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;

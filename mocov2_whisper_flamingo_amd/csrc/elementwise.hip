@@ -118,8 +118,10 @@ __global__ __launch_bounds__(256) void gated_residual_fwd_kernel(const T* __rest
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void gated_residual_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                                  const float* __restrict__ gate, T* __restrict__ dy,
-                                                                 float* __restrict__ dgate, long n, float pdrop, uint64_t seed) {
+                                                                 float* __restrict__ dgate, long n, float pdrop, uint64_t seed_in,
+                                                                 const uint64_t* __restrict__ seed_delta) {
     __shared__ float red[16];
+    const uint64_t seed = avsr_run_seed(seed_in, seed_delta);
     const float g = tanhf(gate[0]);
     const float ks = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -219,7 +221,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, long n, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1, float bc2,
-                                                    const float* __restrict__ grad_scale, int clear_grad) {
+                                                    const float* __restrict__ grad_scale, int clear_grad,
+                                                    const float* __restrict__ hyper, float* __restrict__ reset_word) {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }     // per-step scalars of a step replayed from a graph
+    if (reset_word && blockIdx.x == 0 && threadIdx.x == 0) *reset_word = 0.f;
     const float gs = grad_scale ? grad_scale[0] : 1.f;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -384,6 +389,12 @@ extern "C" int avsr_gated_residual_fwd(avsr_stream_t stream, int dtype, const vo
 
 extern "C" int avsr_gated_residual_bwd(avsr_stream_t stream, int dtype, const void* dout, const void* y, const float* gate,
                                        void* dy, float* dgate, int64_t n, float p_drop, uint64_t seed) {
+    return avsr_gated_residual_bwd_sd(stream, dtype, dout, y, gate, dy, dgate, n, p_drop, seed, nullptr);
+}
+
+extern "C" int avsr_gated_residual_bwd_sd(avsr_stream_t stream, int dtype, const void* dout, const void* y, const float* gate,
+                                          void* dy, float* dgate, int64_t n, float p_drop, uint64_t seed,
+                                          const uint64_t* seed_delta) {
     if (!dout || !y || !gate || !dy || !dgate || n <= 0 || p_drop < 0.f || p_drop >= 1.f) return AVSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (dtype != AVSR_F32 && dtype != AVSR_BF16) return AVSR_EINVAL;
@@ -394,7 +405,7 @@ extern "C" int avsr_gated_residual_bwd(avsr_stream_t stream, int dtype, const vo
     long blocks = (n + 32767) / 32768;
     blocks = blocks < 64 ? 64 : (blocks > 512 ? 512 : blocks);
     dim3 grid(grid_for(n, vec ? 2048 : 256, blocks)), block(256);
-#define L(T, V) hipLaunchKernelGGL((gated_residual_bwd_kernel<T, V>), grid, block, 0, s, (const T*)dout, (const T*)y, gate, (T*)dy, dgate, (long)n, p_drop, seed)
+#define L(T, V) hipLaunchKernelGGL((gated_residual_bwd_kernel<T, V>), grid, block, 0, s, (const T*)dout, (const T*)y, gate, (T*)dy, dgate, (long)n, p_drop, seed, seed_delta)
     if (dtype == AVSR_F32) { if (vec) L(float, true); else L(float, false); }
     else { if (vec) L(bf16_t, true); else L(bf16_t, false); }
 #undef L
@@ -472,7 +483,32 @@ extern "C" int avsr_adamw_step(avsr_stream_t stream, float* param, float* grad, 
     if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return AVSR_EINVAL;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, (bf16_t*)bf16_shadow, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, clear_grad);
+                       exp_avg_sq, (bf16_t*)bf16_shadow, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, clear_grad,
+                       (const float*)nullptr, (float*)nullptr);
+    return avsr_launch_status();
+}
+
+struct StepRecord { unsigned long long seed_delta; float lr, bc1, bc2; unsigned int pad[3]; };
+static_assert(sizeof(StepRecord) == 32, "the step record is 32 bytes");
+__global__ void step_params_kernel(StepRecord* rec, StepRecord v) { *rec = v; }
+
+extern "C" int avsr_step_params(avsr_stream_t stream, void* record, uint64_t seed_delta, float lr, float beta1, float beta2,
+                                int64_t step) {
+    if (!record || step <= 0 || ((uintptr_t)record % 8) != 0) return AVSR_EINVAL;
+    StepRecord v{};
+    v.seed_delta = seed_delta; v.lr = lr;
+    v.bc1 = 1.f - powf(beta1, (float)step); v.bc2 = 1.f - powf(beta2, (float)step);      // as avsr_adamw_step computes them
+    hipLaunchKernelGGL(step_params_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (StepRecord*)record, v);
+    return avsr_launch_status();
+}
+
+extern "C" int avsr_adamw_step_dev(avsr_stream_t stream, float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                                   void* bf16_shadow, int64_t n, const float* hyper, float beta1, float beta2, float eps,
+                                   float weight_decay, const float* grad_scale, int clear_grad, float* clip_scale_reset) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n <= 0) return AVSR_EINVAL;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, (bf16_t*)bf16_shadow, (long)n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_scale,
+                       clear_grad, hyper, clip_scale_reset);
     return avsr_launch_status();
 }
 

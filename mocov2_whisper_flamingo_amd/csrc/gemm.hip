@@ -19,6 +19,7 @@ struct GemmP {
     int tiles_m, tiles_n, vec_ok;
     // extended epilogue (dense products only): second output, dropout, multiply by gelu'(aux)
     void* pre; long ldp; const void* aux; long ldaux; float p_drop; unsigned long long seed; int ext;
+    const unsigned long long* seed_delta;
 };
 
 // Block id -> (tile_m, tile_n).  Blocks are dealt round-robin over the 8 XCDs;
@@ -98,7 +99,8 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, f32x4 acc, int m, 
             if (p.pre) ((OutT*)p.pre)[cbase + (long)m * p.ldp + n] = from_f32<OutT>(pre[r]);
             if (p.aux) v[r] *= gelu_erf_grad(to_f32<OutT>(((const OutT*)p.aux)[(long)m * p.ldaux + n]));
             if (p.p_drop > 0.f)
-                v[r] = avsr_keep(p.seed, (uint64_t)((long)m * p.N + n), p.p_drop) ? v[r] * (1.0f / (1.0f - p.p_drop)) : 0.f;
+                v[r] = avsr_keep(avsr_run_seed(p.seed, (const uint64_t*)p.seed_delta), (uint64_t)((long)m * p.N + n), p.p_drop)
+                           ? v[r] * (1.0f / (1.0f - p.p_drop)) : 0.f;
         }
     }
     OutT* cp = (OutT*)p.C + cbase + (long)m * p.ldc + nb;
@@ -186,6 +188,8 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
     const bool ext_vec = EXT && p.ext == 2;
     const bool has_res = p.res != nullptr;
     const bool stats = p.csum != nullptr;
+    uint64_t run_seed = 0;
+    if constexpr (EXT) run_seed = avsr_run_seed(p.seed, (const uint64_t*)p.seed_delta);
 #pragma unroll
     for (int h = 0; h < NPASS; ++h) {
         __syncthreads();
@@ -234,7 +238,7 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                 if constexpr (EXT) {
                     if (p.aux) x *= gelu_erf_grad_fast(av[e]);
                     if (p.p_drop > 0.f)
-                        x = avsr_keep(p.seed, (uint64_t)((long)m * p.N + n + e), p.p_drop) ? x * (1.0f / (1.0f - p.p_drop)) : 0.f;
+                        x = avsr_keep(run_seed, (uint64_t)((long)m * p.N + n + e), p.p_drop) ? x * (1.0f / (1.0f - p.p_drop)) : 0.f;
                 }
                 v[e] = x;
             }
@@ -798,7 +802,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     p.H = g->conv.H; p.W = g->conv.W; p.Cc = g->conv.C; p.KH = g->conv.KH; p.KW = g->conv.KW;
     p.stride = g->conv.stride; p.pad_h = g->conv.pad_h; p.pad_w = g->conv.pad_w; p.OH = g->conv.OH; p.OW = g->conv.OW;
     p.pre = g->pre; p.ldp = g->ldp; p.aux = g->mul_gelu_grad_of; p.ldaux = g->ld_aux;
-    p.p_drop = g->p_drop; p.seed = g->seed;
+    p.p_drop = g->p_drop; p.seed = g->seed; p.seed_delta = (const unsigned long long*)g->seed_delta;
     p.ext = (g->pre || g->mul_gelu_grad_of || g->p_drop > 0.f || !g->C) ? 1 : 0;
     if (p.ext) {
         const size_t osz_ = g->out_dtype == AVSR_BF16 ? 2 : 4;

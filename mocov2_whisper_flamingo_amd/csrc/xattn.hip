@@ -151,9 +151,9 @@ extern "C" int avsr_gated_xattn_fwd(avsr_stream_t s, const avsr_xattn_block_t* b
             g.g.bias = b->b_in + d;
             TRY(g.run(s));
         }
-        TRY(avsr_attn_fwd(s, dt, dt == AVSR_BF16 ? 1 : 0, w + L.q, d, w + L.kv, 2 * d, w + L.kv + (size_t)d * es, 2 * d,
-                          w + L.ao, d, key_mask, (float*)(w + L.lse), b->B, b->H, b->Tq, b->Tk, 64, 0.125f, b->p_drop,
-                          b->seed_attn, 0));
+        TRY(avsr_attn_fwd_sd(s, dt, dt == AVSR_BF16 ? 1 : 0, w + L.q, d, w + L.kv, 2 * d, w + L.kv + (size_t)d * es, 2 * d,
+                             w + L.ao, d, key_mask, (float*)(w + L.lse), b->B, b->H, b->Tq, b->Tk, 64, 0.125f, b->p_drop,
+                             b->seed_attn, b->seed_delta, 0, nullptr, 0));
         {   // x1 = x + tanh(g_a) * y1,  y1 = ao Wo^T + bo
             G g(dt, M, d, d, w + L.ao, d, b->w_out, d, w + L.x1, d);
             g.g.bias = b->b_out; g.g.residual = x; g.g.ldr = d; g.g.gate = b->gate_attn;
@@ -174,6 +174,7 @@ extern "C" int avsr_gated_xattn_fwd(avsr_stream_t s, const avsr_xattn_block_t* b
         G g(dt, M, d, dff, w + L.f, dff, b->w_fc2, dff, out, d);
         g.g.bias = b->b_fc2; g.g.residual = x1; g.g.ldr = d; g.g.gate = b->gate_ff;
         g.g.pre = w + L.y2; g.g.ldp = d; g.g.p_drop = b->p_drop; g.g.seed = b->seed_ff;
+        g.g.seed_delta = b->seed_delta;
         TRY(g.run(s));
     }
     return AVSR_OK;
@@ -200,7 +201,8 @@ extern "C" int avsr_gated_xattn_bwd(avsr_stream_t s, const avsr_xattn_block_t* b
 
     // ---- feed-forward half -----------------------------------------------------------------------------------
     // dy2 = tanh(g_f) * dropout(dout);  dg_f += (1 - tanh^2) * sum(dout * dropout(y2))
-    TRY(avsr_gated_residual_bwd(s, dt, dout, sv + L.y2, b->gate_ff, w + W.dy, gr->dgate_ff, M * d, b->p_drop, b->seed_ff));
+    TRY(avsr_gated_residual_bwd_sd(s, dt, dout, sv + L.y2, b->gate_ff, w + W.dy, gr->dgate_ff, M * d, b->p_drop, b->seed_ff,
+                                   b->seed_delta));
     {   // du = (dy2 W2) * gelu'(u)
         G g(dt, M, dff, d, w + W.dy, d, b->w_fc2T, b->ld_fc2T, w + W.du, dff);
         g.g.mul_gelu_grad_of = sv + L.u; g.g.ld_aux = dff;
@@ -225,10 +227,10 @@ extern "C" int avsr_gated_xattn_bwd(avsr_stream_t s, const avsr_xattn_block_t* b
         TRY(g.run(s));
     }
     TRY(param_grads(s, dt, w + W.dy, d, sv + L.ao, d, M, d, d, gr->dw_out, d, gr->db_out, w + W.tA, w + W.tB));
-    TRY(avsr_attn_bwd(s, dt, dt == AVSR_BF16 ? 1 : 0, sv + L.q, d, sv + L.kv, 2 * d, sv + L.kv + (size_t)d * es, 2 * d,
-                      sv + L.ao, d, w + W.dao, d, w + W.dq, d, w + W.dkv, 2 * d, w + W.dkv + (size_t)d * es, 2 * d, key_mask,
-                      (const float*)(sv + L.lse), (float*)(w + W.dws), b->B, b->H, b->Tq, b->Tk, 64, 0.125f, b->p_drop,
-                      b->seed_attn));
+    TRY(avsr_attn_bwd_sd(s, dt, dt == AVSR_BF16 ? 1 : 0, sv + L.q, d, sv + L.kv, 2 * d, sv + L.kv + (size_t)d * es, 2 * d,
+                         sv + L.ao, d, w + W.dao, d, w + W.dq, d, w + W.dkv, 2 * d, w + W.dkv + (size_t)d * es, 2 * d, key_mask,
+                         (const float*)(sv + L.lse), (float*)(w + W.dws), b->B, b->H, b->Tq, b->Tk, 64, 0.125f, b->p_drop,
+                         b->seed_attn, b->seed_delta));
     {   // dh1 = dq Wq   (W^T columns [0, d))
         G g(dt, M, d, d, w + W.dq, d, b->w_inT, b->ld_inT, w + W.dh, d);
         TRY(g.run(s));

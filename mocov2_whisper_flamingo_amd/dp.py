@@ -376,3 +376,143 @@ def one_cycle_lr(step, total_steps, max_lr=1e-3, pct_start=0.1, div_factor=25.0,
         return initial + pct * (max_lr - initial)
     pct = (step - up_end) / (down_end - up_end)
     return max_lr + pct * (min_lr - max_lr)
+
+
+class GraphedTail:
+    """The trainable tail of a training step - fusion, vocabulary head, both losses, backward, the gradient
+    exchange, global-norm clip, AdamW and the refresh of the compute-dtype weight copies
+    (train.py:143-170,218-246) - replayed from HIP graphs instead of being enqueued kernel by kernel: the tail
+    is a dependent chain of about 150 short kernels, and enqueuing it costs the host more than the GPU takes to
+    run it.
+
+    ``step(batch, encoded)`` = ``trainer.zero_grad(); model.training_step(batch, encoded=encoded);
+    loss.backward(); trainer.reduce_gradients(); trainer.step(lr)``.  The first ``warmup`` calls run exactly
+    that, eagerly; the next call records two graphs over static copies of the tail's inputs (forward + backward,
+    and clip + AdamW + weight refresh; the gradient all-reduce runs between them, outside any graph) and every
+    later call replays them.  What changes from step to step - the dropout seeds, the learning rate, AdamW's
+    bias corrections - is read by the recorded kernels from a 32-byte device record that one small launch
+    rewrites before each replay (``ops.step_params``).
+
+    Requirements: ``FlatTrainer(fused_step=True, overlap=False, grad_stream=False, dp_mode="allreduce")`` (the
+    gradient buffer is left zeroed by the optimizer kernel, every kernel of the tail runs on the caller's
+    stream), fused cross-attention blocks, and a fixed batch shape.  The returned loss tensors and logits are
+    the recording's static buffers: the next call overwrites them.
+    """
+
+    def __init__(self, trainer, warmup=2):
+        if not (trainer.fused_step and not trainer.overlap and trainer.grad_stream is None and trainer.shard is None):
+            raise ValueError("GraphedTail needs FlatTrainer(fused_step=True, overlap=False, grad_stream=False, "
+                             'dp_mode="allreduce")')
+        if trainer.accumulate != 1:
+            raise ValueError("GraphedTail records one backward pass per optimizer step (accumulate=1)")
+        self.trainer, self.model = trainer, trainer.model
+        self.warmup = int(warmup)
+        self.calls = 0
+        self.rec = None
+        self.failed = None
+
+    # ---- the two halves, as they are recorded -------------------------------------------------------------
+    def _forward_backward(self, batch, encoded):
+        loss, ctc, ce, logits = self.model.training_step(batch, encoded=encoded)
+        loss.backward()
+        return loss, ctc, ce, logits
+
+    def _optimizer(self, record):
+        tr = self.trainer
+        scr = tr._scratch                    # [sum of squares (zero on entry), clip factor, norm]
+        ops.sumsq_accumulate(tr.flat_grad, scr[0:1])
+        ops.clip_scale(scr[0:1], tr.max_norm, scr[1:2], scr[2:3], pre_scale=1.0 / tr.world)
+        ops.adamw_step_dev(tr.flat_param, tr.flat_grad, tr.exp_avg, tr.exp_avg_sq, record, betas=tr.betas, eps=tr.eps,
+                           weight_decay=tr.wd, grad_scale=scr[1:2], clear_grad=True, reset=scr[0:1])
+        self.model._cache.refresh_inplace()
+
+    def _eager(self, batch, encoded, lr):
+        tr = self.trainer
+        tr.zero_grad()
+        out = self._forward_backward(batch, encoded)
+        tr.reduce_gradients()
+        tr.step(lr)
+        return out
+
+    # ---- recording ----------------------------------------------------------------------------------------
+    def _record(self, batch, encoded):
+        import torch
+        model, tr = self.model, self.trainer
+        dev = tr.device
+        st = {k: torch.empty_like(batch[k]) for k in ("video_lengths", "target_ids", "audio_lengths", "target_lengths",
+                                                       "audio_mask", "video_mask")}
+        # the tail never reads the raw audio / video (the encoders did): one-element stand-ins carry the identity check
+        st["audio"] = torch.empty((1,), dtype=batch["audio"].dtype, device=dev)
+        st["video"] = torch.empty((1,), dtype=batch["video"].dtype, device=dev)
+        s_enc = {"enc": torch.empty_like(encoded["enc"]), "vis": torch.empty_like(encoded["vis"]), "done": [],
+                 "inputs": model.batch_inputs(st)}
+        record = torch.zeros(4, dtype=torch.int64, device=dev)          # the 32-byte step record
+        self._fill(st, s_enc, batch, encoded)
+        step0, count0 = model._step, tr.step_count
+        tr.join_gradients()
+        if tr._clean:
+            tr._clean = False
+        else:
+            tr.flat_grad.zero_()
+        tr._scratch.zero_()
+        model._cache.refresh()                # every compute-dtype weight copy current, allocated outside the recording
+        model._seed_delta = record
+        torch.cuda.current_stream().synchronize()
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                outs = self._forward_backward(st, s_enc)
+            pool = g1.pool()
+            with torch.cuda.graph(g2, pool=pool, capture_error_mode="thread_local"):
+                self._optimizer(record)
+        finally:
+            model._seed_delta = None
+            model._step = step0               # the recording consumed a step number without running a step
+        self.rec = {"g1": g1, "g2": g2, "st": st, "enc": s_enc, "record": record, "outs": outs, "step_cap": step0 + 1}
+        tr.step_count = count0
+
+    @staticmethod
+    def _fill(st, s_enc, batch, encoded):
+        for k, dst in st.items():
+            if k not in ("audio", "video"):
+                dst.copy_(batch[k], non_blocking=True)
+        s_enc["enc"].copy_(encoded["enc"], non_blocking=True)
+        s_enc["vis"].copy_(encoded["vis"], non_blocking=True)
+
+    # ---- one step -----------------------------------------------------------------------------------------
+    def step(self, batch, encoded, lr=None):
+        """One optimizer step on ``batch`` whose frozen encoders were issued as ``encoded`` (AVNet.encode).
+        Returns (loss, ctc, ce, logits)."""
+        import torch
+        model, tr = self.model, self.trainer
+        self.calls += 1
+        if self.rec is None and self.failed is None and self.calls > self.warmup:
+            main = torch.cuda.current_stream()
+            for stream, ev in encoded["done"]:
+                main.wait_event(ev)
+            try:
+                self._record(batch, encoded)
+            except RuntimeError as e:           # a runtime that refuses the capture: keep training, launch by launch
+                self.failed = repr(e)
+        if self.rec is None:
+            return self._eager(batch, encoded, lr)
+        rec = self.rec
+        if encoded["inputs"][0] is not batch["audio"] or encoded["inputs"][2] is not batch["video"]:
+            raise ValueError("`encoded` was computed for a different batch")
+        main = torch.cuda.current_stream()
+        for stream, ev in encoded["done"]:
+            main.wait_event(ev)
+        for tns in (encoded["enc"], encoded["vis"]):
+            tns.record_stream(main)
+        self._fill(rec["st"], rec["enc"], batch, encoded)
+        model._step += 1
+        tr.step_count += 1
+        delta = ((model._step - rec["step_cap"]) * model.SEED_STEP_MUL) & 0xFFFFFFFFFFFFFFFF
+        ops.step_params(rec["record"], delta, tr.lr if lr is None else lr, tr.betas, tr.step_count)
+        rec["g1"].replay()
+        tr.reduce_gradients()                 # the all-reduce (world > 1), in stream order between the two graphs
+        rec["g2"].replay()
+        tr._pre_scale = 1.0
+        tr._clean = True
+        batch["video_lengths"].copy_(rec["st"]["video_lengths"], non_blocking=True)    # clamped in place, as forward does
+        return rec["outs"]

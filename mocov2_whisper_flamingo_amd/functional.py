@@ -61,6 +61,21 @@ class WeightCache:
         self._store[key] = (ver, wc, wct, p)
         return wc, wct
 
+    def refresh_inplace(self):
+        """Recompute every cached copy INTO its existing buffers on the current stream, and mark them current.
+        For an owner that updates the parameters in place and keeps every reader on this one stream (a training
+        step recorded in a HIP graph: the recorded kernels keep reading the same addresses)."""
+        with torch.no_grad():
+            for key, (ver, wc, wct, p) in list(self._store.items()):
+                w = p.detach()
+                pad = 1024 if w.shape[0] > 16384 else 8
+                if self.dtype == torch.float32:
+                    ops.transpose2d(w, dtype=self.dtype, pad_to=pad, out=wct)
+                    wc = w
+                else:
+                    ops.transpose2d(w, dtype=self.dtype, pad_to=pad, with_copy=True, out=wct, out_copy=wc)
+                self._store[key] = ((p._version, p.data_ptr(), self.epoch), wc, wct, p)
+
     def clear(self):
         self._store.clear()
 

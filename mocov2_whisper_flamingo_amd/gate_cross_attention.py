@@ -38,6 +38,7 @@ class GatedCrossAttentionBlock(nn.Module):
         self.d_model, self.n_heads, self.p_drop = d_model, n_heads, dropout
         self._cache = None          # WeightCache, set by the owner
         self._seed_fn = lambda tag: 0
+        self._seed_delta_fn = lambda: None      # device word added to the dropout seeds at run time (graph replays)
         # fused: the block is ONE autograd node over avsr_gated_xattn_fwd / _bwd (element-wise steps in the GEMM
         # epilogues, one host call per direction); False = the kernel-by-kernel composition, kept for comparison
         self.fused = True
@@ -58,8 +59,11 @@ class GatedCrossAttentionBlock(nn.Module):
         vectors = (prm[1], prm[3], prm[5], prm[7]) + prm[8:]
         blk = Fn.ops.xattn_block_desc(x.dtype, B, T, Tk, d, self.n_heads, self.ff[0].weight.shape[0], p,
                                       self._seed_fn("attn") if p > 0 else 0, self._seed_fn("ff") if p > 0 else 0,
-                                      weights, [v.detach() for v in vectors])
-        km = None if (mask is None or xa is None) else mask.to(torch.uint8).contiguous()
+                                      weights, [v.detach() for v in vectors],
+                                      seed_delta=self._seed_delta_fn() if p > 0 else None)
+        km = None
+        if mask is not None and xa is not None:     # a bool mask is read as bytes where it lies (no copy kernel)
+            km = mask.view(torch.uint8) if (mask.dtype == torch.bool and mask.is_contiguous()) else mask.to(torch.uint8).contiguous()
         x2 = x.reshape(B * T, d)
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
         xa2 = None
@@ -121,12 +125,14 @@ class GatedCrossModalFusion(nn.Module):
         self.ln_post = LayerNorm(d_model)
         self.set_runtime(Fn.WeightCache(dtype), lambda tag: 0)
 
-    def set_runtime(self, cache, seed_fn):
+    def set_runtime(self, cache, seed_fn, seed_delta_fn=None):
         """Share one weight cache / dropout-seed source with the owning AVNet."""
         self._cache = cache
         for i, layer in enumerate(self.layers):
             layer._cache = cache
             layer._seed_fn = (lambda tag, i=i: seed_fn(f"fusion.{i}.{tag}"))
+            if seed_delta_fn is not None:
+                layer._seed_delta_fn = seed_delta_fn
 
     def forward(self, audio_features, video_features, audio_mask=None, video_mask=None):
         """``audio_mask`` is accepted and unused, as in the reference

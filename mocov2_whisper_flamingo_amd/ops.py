@@ -536,10 +536,12 @@ def cast_rows(x, out, scale=1.0):
     return out
 
 
-def transpose2d(x, dtype=None, scale=1.0, pad_to=1, with_copy=False):
+def transpose2d(x, dtype=None, scale=1.0, pad_to=1, with_copy=False, out=None, out_copy=None):
     """[..., R, C] (row-major, row stride may exceed C) -> [..., C, Rp] contiguous, Rp = R rounded up
     to a multiple of ``pad_to`` with the padding columns zero (optionally converting dtype).
-    ``with_copy`` (2-D only) also returns the untransposed tensor in the output dtype: (y^T, y)."""
+    ``with_copy`` (2-D only) also returns the untransposed tensor in the output dtype: (y^T, y).
+    ``out`` / ``out_copy``: buffers of an earlier call with the same arguments, rewritten in place (their padding
+    columns are already zero and are not touched)."""
     lib = _lib.load()
     if x.stride(-1) != 1 or (x.dim() > 2 and not x.is_contiguous()):
         x = x.contiguous()
@@ -547,9 +549,19 @@ def transpose2d(x, dtype=None, scale=1.0, pad_to=1, with_copy=False):
     ldx = x.stride(-2)
     Rp = (R + pad_to - 1) // pad_to * pad_to
     batch = x.numel() // (R * C)
-    alloc = torch.zeros if Rp != R else torch.empty
-    y = alloc((*x.shape[:-2], C, Rp), dtype=dtype or x.dtype, device=x.device)
-    cp = torch.empty((R, C), dtype=y.dtype, device=x.device) if with_copy else None
+    if out is not None:
+        if tuple(out.shape) != (*x.shape[:-2], C, Rp) or not out.is_contiguous() or (dtype and out.dtype != dtype):
+            raise ValueError("transpose2d: `out` does not match")
+        y = out
+    else:
+        alloc = torch.zeros if Rp != R else torch.empty
+        y = alloc((*x.shape[:-2], C, Rp), dtype=dtype or x.dtype, device=x.device)
+    if with_copy and out_copy is not None:
+        if tuple(out_copy.shape) != (R, C) or not out_copy.is_contiguous() or out_copy.dtype != y.dtype:
+            raise ValueError("transpose2d: `out_copy` does not match")
+        cp = out_copy
+    else:
+        cp = torch.empty((R, C), dtype=y.dtype, device=x.device) if with_copy else None
     check(lib.avsr_transpose(_stream(), _dt(x), _DT[y.dtype], x.data_ptr(), ldx, R * ldx, y.data_ptr(), Rp, C * Rp, batch,
                              R, C, scale, _p(cp), C), "avsr_transpose")
     return (y, cp) if with_copy else y
@@ -628,7 +640,7 @@ def add3(a, b, c=None):
     return out
 
 
-def xattn_block_desc(dtype, B, Tq, Tk, d, H, d_ff, p_drop, seed_attn, seed_ff, weights, vectors):
+def xattn_block_desc(dtype, B, Tq, Tk, d, H, d_ff, p_drop, seed_attn, seed_ff, weights, vectors, seed_delta=None):
     """Descriptor of one gated cross-attention block for gated_xattn_fwd / _bwd.  ``weights`` = four (W, W^T)
     pairs in ``dtype`` for in_proj, out_proj, ff.0, ff.2 (W as nn.Linear stores it, W^T [in, ld >= out]);
     ``vectors`` = fp32 tensors (b_in, b_out, b_fc1, b_fc2, ln1_g, ln1_b, ln2_g, ln2_b, gate_attn, gate_ff).
@@ -636,6 +648,8 @@ def xattn_block_desc(dtype, B, Tq, Tk, d, H, d_ff, p_drop, seed_attn, seed_ff, w
     blk = _lib.XattnBlock()
     blk.dtype, blk.B, blk.Tq, blk.Tk, blk.d, blk.H, blk.d_ff = _DT[dtype], B, Tq, Tk, d, H, d_ff
     blk.p_drop, blk.seed_attn, blk.seed_ff = float(p_drop), int(seed_attn), int(seed_ff)
+    # seed_delta: a device tensor whose first 8 bytes are added to both seeds when the kernels run (graph replays)
+    blk.seed_delta = _p(seed_delta)
     _need_cuda(*vectors)
     for name, (w, wt) in zip(("in", "out", "fc1", "fc2"), weights):
         _need_cuda(w, wt)
@@ -649,7 +663,7 @@ def xattn_block_desc(dtype, B, Tq, Tk, d, H, d_ff, p_drop, seed_attn, seed_ff, w
         if v.dtype != torch.float32 or not v.is_contiguous():
             raise ValueError(f"{name} must be a contiguous fp32 tensor")
         setattr(blk, name, v.data_ptr())
-    blk._keep = (weights, vectors)
+    blk._keep = (weights, vectors, seed_delta)
     return blk
 
 
@@ -752,3 +766,21 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, step, *, lr, betas=(0.9, 0.98),
     check(lib.avsr_adamw_step(_stream(), param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                               _p(bf16_shadow), param.numel(), lr, betas[0], betas[1], eps, weight_decay, step,
                               _p(grad_scale), int(bool(clear_grad))), "avsr_adamw_step")
+
+
+def step_params(record, seed_delta, lr, betas, step):
+    """Write one training step's scalars (dropout seed offset, learning rate, AdamW bias corrections for ``step``)
+    into the 32-byte device ``record`` that graph-recorded kernels read; the values travel as kernel arguments."""
+    lib = _lib.load()
+    check(lib.avsr_step_params(_stream(), record.data_ptr(), int(seed_delta) & 0xFFFFFFFFFFFFFFFF, float(lr), betas[0],
+                               betas[1], int(step)), "avsr_step_params")
+
+
+def adamw_step_dev(param, grad, exp_avg, exp_avg_sq, record, *, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01,
+                   grad_scale=None, clear_grad=False, reset=None):
+    """adamw_step with lr and the bias corrections read from ``record`` (see step_params); ``reset``: a device float
+    set to zero by the launch (the sum of squares of the step's clip factor)."""
+    lib = _lib.load()
+    check(lib.avsr_adamw_step_dev(_stream(), param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                  None, param.numel(), record.data_ptr() + 8, betas[0], betas[1], eps, weight_decay,
+                                  _p(grad_scale), int(bool(clear_grad)), _p(reset)), "avsr_adamw_step_dev")

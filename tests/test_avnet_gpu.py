@@ -335,6 +335,58 @@ def test_avnet_forward_and_training_step(dev, dtype):
     assert params["fusion_scalar"].grad is None
 
 
+@pytest.mark.parametrize("lr_schedule", [False, True])
+def test_trainable_tail_replayed_from_graphs(dev, lr_schedule):
+    """GraphedTail: six optimizer steps in train mode (batch-statistics BN, both dropouts, a different batch and -
+    optionally - a different learning rate every step), the last four replayed from the recorded graphs, against
+    the same steps enqueued kernel by kernel.  Every step's loss and logits agree to the summation order of the
+    fp32 atomics in the LayerNorm / gate gradients of the steps before it (a replay that drew the wrong dropout
+    masks, learning rate or bias corrections would be off by orders of magnitude more), and so do the final
+    weights and the last gradient norm."""
+    import copy
+    from mocov2_whisper_flamingo_amd.dp import FlatTrainer, GraphedTail, one_cycle_lr
+    m0, _ = _micro_avnet(torch.bfloat16, dev, p_drop=0.1)
+    m0.train()
+    batches = [to_device(synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=40 + s), dev) for s in range(6)]
+    runs = []
+    for graphed in (False, True):
+        m = copy.deepcopy(m0)
+        tr = FlatTrainer(m, lr=1e-3, bucket_mb=0.25, overlap=False, grad_stream=False, fused_step=True)
+        tail = GraphedTail(tr, warmup=2 if graphed else 10 ** 9)
+        outs = []
+        for i, b0 in enumerate(batches):
+            b = dict(b0, video_lengths=b0["video_lengths"].clone())
+            enc = m.encode(m.batch_inputs(b))
+            lr = one_cycle_lr(i, 20, max_lr=1e-3) if lr_schedule else None
+            loss, ctc, ce, logits = tail.step(b, enc, lr=lr)
+            outs.append((loss.detach().clone(), ctc.detach().clone(), logits.detach().clone()))
+        torch.cuda.synchronize()
+        assert tail.failed is None
+        assert (tail.rec is not None) == graphed
+        assert m._step == len(batches) and tr.step_count == len(batches)
+        runs.append((outs, {k: p.detach().clone() for k, p in m.named_parameters()}, tr.grad_norm().clone()))
+    (eo, ep, en), (go, gp, gn) = runs
+    for i, ((l, c, lg), (rl, rc, rlg)) in enumerate(zip(go, eo)):
+        if i == 0:                       # identical weights and masks (later steps: the atomics' summation order)
+            assert torch.equal(l, rl) and torch.equal(lg, rlg), i
+        else:
+            assert abs(l.item() - rl.item()) <= 2e-3 * abs(rl.item()), i
+            assert max_err(lg, rlg) < 5e-3, i
+    assert abs(gn.item() - en.item()) <= 1e-2 * en.item()
+    # AdamW normalises every gradient element by its own running magnitude, so elements whose gradient is rounding
+    # noise (the key bias of the attention, which softmax cannot see) move by +-lr per step whatever their sign
+    # noise says: the weights are compared through their UPDATES - same length and direction for every matrix -
+    # and element by element only against that worst case
+    from mocov2_whisper_flamingo_amd.dp import trainable_parameters
+    p0 = dict(m0.named_parameters())
+    for k, _ in trainable_parameters(m0):
+        ug, ue = (gp[k] - p0[k]).float().reshape(-1), (ep[k] - p0[k]).float().reshape(-1)
+        assert (ug - ue).abs().max() <= 2 * 1e-3 * len(batches), k
+        if ue.numel() >= 4096:
+            assert abs(ug.norm().item() / ue.norm().item() - 1.0) <= 2e-2, k
+            assert torch.dot(ug, ue).item() >= 0.98 * ug.norm().item() * ue.norm().item(), k
+
+
 def test_avnet_generic_loss_backward(dev):
     """Drop-in use: the caller puts its own torch loss on the returned logits."""
     dtype = torch.float32
