@@ -340,6 +340,24 @@ int64_t avsr_bn_finalize_workspace_floats(int64_t C);
 int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq, int64_t nparts, double count,
                      const float* weight, const float* bias, float* running_mean, float* running_var,
                      float* scale, float* shift, int64_t C, float eps, float momentum, float* ws, int32_t* tickets);
+/* Batch statistics of a 1x1 convolution's OUTPUT from the second moments of its INPUT: for y = W h per pixel,
+ * mean(y_c) = w_c . mean(h) and mean(y_c^2) = w_c^T mean(h h^T) w_c.  With them known before the convolution runs,
+ * the expanding convolution of a torchvision Bottleneck (conv3 + bn3 in training mode + residual + ReLU,
+ * models/moco_visual_frontend.py:20,45) applies the normalisation in its own epilogue (avsr_gemm_nt with scale /
+ * bias / residual / AVSR_ACT_RELU_AFTER_RESIDUAL) instead of storing the raw product for a second pass.
+ * avsr_gram_stats: X bf16 [M, K] (row pitch ldx), K = 64 or 128 -> gram_parts fp32 [parts, K, K] and colsum_parts
+ * fp32 [parts, K], parts = avsr_gram_parts(M, K): per-share partial sums, plain stores, added in share order later.
+ * avsr_bn_gram_finalize: W bf16 [N, K] (the convolution's weight as the product reads it), count = M; writes scale /
+ * shift for the N output channels and updates the running statistics exactly as avsr_bn_finalize does.
+ * workspace: avsr_bn_gram_workspace_doubles(K) doubles. */
+int64_t avsr_gram_parts(int64_t M, int64_t K);
+int avsr_gram_stats(avsr_stream_t stream, const void* X, int64_t ldx, int64_t M, int64_t K, float* gram_parts,
+                    float* colsum_parts);
+int64_t avsr_bn_gram_workspace_doubles(int64_t K);
+int avsr_bn_gram_finalize(avsr_stream_t stream, const float* gram_parts, const float* colsum_parts, int64_t parts,
+                          int64_t K, double count, const void* W_bf16, int64_t ldw, int64_t N, const float* weight,
+                          const float* bias, float* running_mean, float* running_var, float* scale, float* shift,
+                          float eps, float momentum, double* workspace);
 int avsr_bn_fold(avsr_stream_t stream, const float* weight, const float* bias, const float* running_mean,
                  const float* running_var, float* scale, float* shift, int64_t C, float eps);
 /* y = act(x*scale + shift (+ residual)); x may be fp32 while y / residual are bf16.  res_scale / res_shift

@@ -93,6 +93,11 @@ SIGNATURES = {
     "avsr_bn_finalize_workspace_floats": (_i64, [_i64]),
     "avsr_gemm_stats_parts": (_i64, [_i32, _i64]),
     "avsr_stem3d_stats_parts": (_i64, [_i64, _i64, _i64, _i64]),
+    "avsr_gram_parts": (_i64, [_i64, _i64]),
+    "avsr_gram_stats": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "avsr_bn_gram_workspace_doubles": (_i64, [_i64]),
+    "avsr_bn_gram_finalize": (_i32, [_vp, _vp, _vp, _i64, _i64, _f64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _f32, _f32, _vp]),
     "avsr_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32]),
     "avsr_bn_apply": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32]),
     "avsr_head_loss_workspace_floats": (_i64, [_i64, _i64, _i64]),

@@ -161,7 +161,10 @@ __device__ __forceinline__ void stats_quad(const GemmP& p, f32x4 s, f32x4 s2, in
 // costs several scalar branches per element) and the row loop is NOT unrolled: the epilogue runs once per
 // tile, so its instructions are fetched cold, and straight-line code four times as long measured 17-30 %
 // slower on the K = 768 encoder GEMMs (instruction-cache misses, not arithmetic).
-template <int BN_, typename OutT, int ACT, bool CONV, int MI, bool EXT = false>
+// RESPF (products with a residual operand): the residual rows of a pass are requested before the pass's LDS staging and
+// used from registers - in the rolled row loop every iteration would wait for its own residual load, eight to ten exposed
+// memory latencies per tile; the row loop of these instantiations is unrolled instead (2 or 4 iterations).
+template <int BN_, typename OutT, int ACT, bool CONV, int MI, bool EXT = false, bool RESPF = false>
 __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][BN_ / 32], char* lds, const float* sb,
                                               int m0, int n0, int tm, long cbase, int lane, int wave) {
     constexpr int NJ = BN_ / 32, LDT = BN_ + 4, CG = BN_ / 8, RS = 256 / CG;
@@ -190,8 +193,23 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
     const bool stats = p.csum != nullptr;
     uint64_t run_seed = 0;
     if constexpr (EXT) run_seed = avsr_run_seed(p.seed, (const uint64_t*)p.seed_delta);
+    constexpr int NIT = (PROWS + RS - 1) / RS, UNR = RESPF ? NIT : 1;
+    constexpr int RW = sizeof(OutT) == 4 ? 2 : 1;       // 16-byte words of residual per thread and row
+    f32x4 rpf[RESPF ? NIT * RW : 1];
 #pragma unroll
     for (int h = 0; h < NPASS; ++h) {
+        if constexpr (RESPF) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int lr = r0 + it * RS;
+                const int m = m0 + (lr / (SUBS * 16)) * (MI * 16) + h * (SUBS * 16) + (lr % (SUBS * 16));
+                if ((PROWS % RS == 0 || lr < PROWS) && m < p.M && full) {
+                    const OutT* rp = (const OutT*)p.res + (long)(p.res_period > 0 ? m % p.res_period : m) * p.ldr + n;
+#pragma unroll
+                    for (int w = 0; w < RW; ++w) rpf[it * RW + w] = *(const f32x4*)((const char*)rp + 16 * w);
+                }
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int ii = 0; ii < SUBS; ++ii)
@@ -200,8 +218,8 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                 *(f32x4*)&Ct[(wm * SUBS * 16 + ii * 16 + (lane & 15)) * LDT + (wn * NJ + j) * 16 + (lane >> 4) * 4] =
                     acc[SUBS * h + ii][j];
         __syncthreads();
-#pragma unroll 1
-        for (int it = 0; it < (PROWS + RS - 1) / RS; ++it) {
+#pragma unroll UNR
+        for (int it = 0; it < NIT; ++it) {
             const int lr = r0 + it * RS;
             if (PROWS % RS != 0 && lr >= PROWS) continue;
             const int m = m0 + (lr / (SUBS * 16)) * (MI * 16) + h * (SUBS * 16) + (lr % (SUBS * 16));
@@ -269,11 +287,15 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
             if (full) {
                 if (has_res) {
                     if constexpr (sizeof(OutT) == 4) {
-                        const f32x4 ra = *(const f32x4*)rp, rb = *(const f32x4*)(rp + 4);
+                        f32x4 ra, rb;
+                        if constexpr (RESPF) { ra = rpf[it * RW]; rb = rpf[it * RW + RW - 1]; }
+                        else { ra = *(const f32x4*)rp; rb = *(const f32x4*)(rp + 4); }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] = fmaf(g, v[e], ra[e]); v[4 + e] = fmaf(g, v[4 + e], rb[e]); }
                     } else {
-                        const bf16x8 rv = *(const bf16x8*)rp;
+                        bf16x8 rv;
+                        if constexpr (RESPF) rv = __builtin_bit_cast(bf16x8, rpf[it * RW]);
+                        else rv = *(const bf16x8*)rp;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = fmaf(g, v[e], (float)rv[e]);
                     }
@@ -340,6 +362,18 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][B
             epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV, MI, true>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
         return;
     }
+#ifndef G_NO_RESPF
+    if (p.res != nullptr) {                     // block-uniform: residual rows requested ahead of each pass
+        if (p.act == AVSR_ACT_NONE) {
+            epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV, MI, false, true>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+            return;
+        }
+        if (p.act == AVSR_ACT_RELU_AFTER_RESIDUAL) {
+            epilogue_body<BN_, OutT, AVSR_ACT_RELU_AFTER_RESIDUAL, CONV, MI, false, true>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+            return;
+        }
+    }
+#endif
     switch (p.act) {                            // block-uniform
         case AVSR_ACT_GELU: epilogue_body<BN_, OutT, AVSR_ACT_GELU, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
         case AVSR_ACT_RELU: epilogue_body<BN_, OutT, AVSR_ACT_RELU, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;

@@ -40,27 +40,33 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* X, int ks, int cb, int l
 // otherwise: more workgroups).  NST-deep ring of 64-row stages: the contraction is short (M/64 = 10 steps for the
 // fusion's 600 rows), so with one stage in flight a step costs a whole memory latency; with NST - 1 in flight only
 // the first does.
-template <int TB, int NST> constexpr int tn_main_bytes() {
-    constexpr int stages = 2 * NST * TB * 64 * 64 * 2, epi = 4 * (32 * TB) * (32 * TB + 4) * 4;
+template <int TB, int NST, bool GRAM = false> constexpr int tn_main_bytes() {
+    constexpr int stages = (GRAM ? 1 : 2) * NST * TB * 64 * 64 * 2, epi = 4 * (32 * TB) * (32 * TB + 4) * 4;
     return stages > epi ? stages : epi;
 }
-template <int TB, int NST> constexpr int tn_lds_bytes() { return tn_main_bytes<TB, NST>() + 4 * 64 * TB * 4; }
+template <int TB, int NST, bool GRAM = false> constexpr int tn_lds_bytes() { return tn_main_bytes<TB, NST, GRAM>() + 4 * 64 * TB * 4; }
 
-template <int TB, int NST>
+// GRAM: the Gram matrix A^T A of ONE tall operand with at most 64*TB columns (B is A: one set of stages, both fragments
+// read from it).  The rows are cut into gridDim.x shares, one workgroup each, on every XCD; share p stores its partial
+// product at C + p * part_stride and its column sums at colsum + p * N with plain stores (no atomics: the caller adds
+// the shares in a fixed order).
+template <int TB, int NST, bool GRAM = false>
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                            long ldb, float* __restrict__ C, long ldc, int M, int N, int K,
                                                            int accumulate, float* __restrict__ colsum, int accumulate_colsum,
-                                                           int ntiles, int ktiles, int nsplit) {
+                                                           int ntiles, int ktiles, int nsplit, long part_stride) {
     constexpr int TILE = 64 * TB, SUB = 64 * 64;              // an operand stage is TB sub-tiles of [64 rows][64 cols]
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     bf16_t* As = (bf16_t*)lds_raw;                            // [NST][TB][SUB]
-    bf16_t* Bs = As + NST * TB * SUB;
-    float* csum = (float*)(lds_raw + tn_main_bytes<TB, NST>());   // [4][TILE], behind the stages / the epilogue blocks
+    bf16_t* Bs = GRAM ? As : As + NST * TB * SUB;
+    float* csum = (float*)(lds_raw + tn_main_bytes<TB, NST, GRAM>());   // [4][TILE], behind the stages / the epilogue blocks
     // nsplit > 1 (long contractions into few tiles): the rows are cut into nsplit shares, one workgroup each, and
     // the shares meet in C and colsum by fp32 atomic adds (accumulating calls only; summation order then varies)
-    const int xcd = blockIdx.x & 7, j = (blockIdx.x >> 3) / nsplit, part = (blockIdx.x >> 3) - j * nsplit;
-    const int kt = j % ktiles, nt = (j / ktiles) * 8 + xcd;
+    const int xcd = blockIdx.x & 7, j = GRAM ? 0 : (blockIdx.x >> 3) / nsplit;
+    const int part = GRAM ? (int)blockIdx.x : (int)(blockIdx.x >> 3) - j * nsplit;
+    const int kt = GRAM ? 0 : j % ktiles, nt = GRAM ? 0 : (j / ktiles) * 8 + xcd;
     if (nt >= ntiles) return;
+    if constexpr (GRAM) { C += (long)part * part_stride; colsum += (long)part * N; }
     const int n0 = nt * TILE, k0 = kt * TILE;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -91,7 +97,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     dma_piece(ab + 128 * sub, offA[i], (const char*)&As[(buf * TB + sub) * SUB + (2 * wave + i) * 512]);
-                    dma_piece(bb + 128 * sub, offB[i], (const char*)&Bs[(buf * TB + sub) * SUB + (2 * wave + i) * 512]);
+                    if constexpr (!GRAM)
+                        dma_piece(bb + 128 * sub, offB[i], (const char*)&Bs[(buf * TB + sub) * SUB + (2 * wave + i) * 512]);
                 }
             return;
         }
@@ -108,12 +115,14 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
                 const uintptr_t pa = zaddr + ((ra - zaddr) & (uintptr_t)(-(long)oka));
                 const uintptr_t pb = zaddr + ((rb - zaddr) & (uintptr_t)(-(long)okb));
                 __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)&As[(buf * TB + sub) * SUB + (2 * wave + i) * 512], 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)&Bs[(buf * TB + sub) * SUB + (2 * wave + i) * 512], 16, 0, 0);
+                if constexpr (!GRAM)
+                    __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)&Bs[(buf * TB + sub) * SUB + (2 * wave + i) * 512], 16, 0, 0);
             }
     };
     auto wait_oldest = [&](bool younger_in_flight) {         // all but the youngest stage's 4*TB loads have landed
         if (NST > 2 && younger_in_flight) {
-            if constexpr (TB == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if constexpr (TB == 1 && GRAM) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if constexpr (TB == 1 || GRAM) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
         if (n >= N || kq >= K) continue;
         const f32x4 v = *(const f32x4*)&ct[row * LDT + qc];
         float* cp = C + (long)n * ldc + kq;
-        if (nsplit > 1) {
+        if (nsplit > 1 && !GRAM) {
             for (int e = 0; e < 4 && kq + e < K; ++e) unsafeAtomicAdd(cp + e, v[e]);      // the hardware fp32 add, no CAS loop
         } else if (vec && kq + 4 <= K) {
             f32x4 o = v;
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
         __syncthreads();
         if (t < TILE && n0 + t < N) {
             const float s = csum[t] + csum[TILE + t] + csum[2 * TILE + t] + csum[3 * TILE + t];
-            if (nsplit > 1) unsafeAtomicAdd(&colsum[n0 + t], s);
+            if (nsplit > 1 && !GRAM) unsafeAtomicAdd(&colsum[n0 + t], s);
             else colsum[n0 + t] = accumulate_colsum ? colsum[n0 + t] + s : s;
         }
     }
@@ -233,11 +242,48 @@ int launch_tn(hipStream_t s, const void* A, int64_t lda, const void* B, int64_t 
     if (grid > 0x7fffffff) return AVSR_EUNSUPPORTED;
     hipLaunchKernelGGL((gemm_tn_bf16_kernel<TB, NST>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)A, (long)lda,
                        (const bf16_t*)B, (long)ldb, C, (long)ldc, (int)M, (int)N, (int)K, accumulate, colsum,
-                       accumulate_colsum, (int)ntiles, (int)ktiles, (int)nsplit);
+                       accumulate_colsum, (int)ntiles, (int)ktiles, (int)nsplit, 0L);
+    return avsr_launch_status();
+}
+
+template <int TB, int NST>
+int launch_gram(hipStream_t s, const void* X, int64_t ldx, int64_t M, int64_t K, int64_t parts, float* G, float* colsum) {
+    constexpr int lds = tn_lds_bytes<TB, NST, true>();
+    static avsr_dev_flags attr_set;
+    if (lds > 48 * 1024 && !avsr_allow_lds((const void*)gemm_tn_bf16_kernel<TB, NST, true>, lds, attr_set)) return AVSR_EHIP;
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<TB, NST, true>), dim3((unsigned)parts), dim3(256), lds, s, (const bf16_t*)X, (long)ldx,
+                       (const bf16_t*)X, (long)ldx, G, (long)K, (int)M, (int)K, (int)K, 0, colsum, 0, 1, 1, (int)parts,
+                       (long)(K * K));
     return avsr_launch_status();
 }
 
 }  // namespace
+
+#ifndef GRAM_CAP64
+#define GRAM_CAP64 512
+#endif
+#ifndef GRAM_CAP128
+#define GRAM_CAP128 256
+#endif
+#ifndef GRAM_MIN_STEPS
+#define GRAM_MIN_STEPS 8
+#endif
+extern "C" int64_t avsr_gram_parts(int64_t M, int64_t K) {
+    if (M <= 0 || (K != 64 && K != 128)) return 0;
+    // shares of at least eight 64-row steps, at most two (K = 64) or one (K = 128) per CU
+    const int64_t steps = (M + 63) / 64, cap = K == 64 ? GRAM_CAP64 : GRAM_CAP128;
+    return std::max<int64_t>(1, std::min<int64_t>(cap, steps / GRAM_MIN_STEPS));
+}
+
+extern "C" int avsr_gram_stats(avsr_stream_t stream, const void* X, int64_t ldx, int64_t M, int64_t K, float* gram_parts,
+                               float* colsum_parts) {
+    if (!X || !gram_parts || !colsum_parts || M <= 0) return AVSR_EINVAL;
+    if (K != 64 && K != 128) return AVSR_EUNSUPPORTED;
+    if (ldx < K || ldx % 8 || (uintptr_t)X % 16 || M > 0x7fffffff || 64 * ldx * 2 > 0x7fffffffLL) return AVSR_EUNSUPPORTED;
+    const int64_t parts = avsr_gram_parts(M, K);
+    if (K == 64) return launch_gram<1, 3>((hipStream_t)stream, X, ldx, M, K, parts, gram_parts, colsum_parts);
+    return launch_gram<2, 3>((hipStream_t)stream, X, ldx, M, K, parts, gram_parts, colsum_parts);
+}
 
 extern "C" int avsr_gemm_tn(avsr_stream_t stream, const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
                             int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, float* colsum,

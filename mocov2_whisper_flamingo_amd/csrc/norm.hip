@@ -539,6 +539,129 @@ __global__ __launch_bounds__(256) void bn_apply_bf16x8_kernel(const bf16_t* x, c
     }
 }
 
+// ---- batch statistics of a 1x1 convolution's OUTPUT from the second moments of its INPUT -----------------------
+// y = W h per pixel, so mean(y_c) = w_c . mean(h) and mean(y_c^2) = w_c^T mean(h h^T) w_c: the K x K Gram matrix of the
+// input (K = 64 / 128 channels) gives the statistics of all 4K output channels without the output existing yet, and the
+// convolution can then apply the normalisation, the residual and the ReLU in its own epilogue instead of storing the
+// raw product for a second pass.  Step 1 (avsr_gram_stats, gemm_tn.hip) leaves per-share partial Gram matrices and
+// column sums; gram_reduce adds the shares in share order (16 waves take interleaved shares, folded in wave order:
+// deterministic) into doubles scaled by 1 / count; bn_gram_finalize evaluates the two forms per output channel.
+__global__ __launch_bounds__(1024) void gram_reduce_kernel(const float* __restrict__ gram_parts, const float* __restrict__ colsum_parts,
+                                                           int parts, int KK, int K, double inv_n, float* __restrict__ out) {
+    __shared__ double red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const bool live = e < KK + K;
+    const float* src = e < KK ? gram_parts + e : colsum_parts + (live ? e - KK : 0);
+    const long stride = e < KK ? KK : K;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (live) {
+        int p = w;
+        for (; p + 48 < parts; p += 64) {
+            const float v0 = src[(long)p * stride], v1 = src[(long)(p + 16) * stride];
+            const float v2 = src[(long)(p + 32) * stride], v3 = src[(long)(p + 48) * stride];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; p < parts; p += 16) a0 += src[(long)p * stride];
+    }
+    red[w][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (w == 0 && live) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][lane];
+        out[e] = (float)(s * inv_n);
+    }
+}
+
+// 8 output channels per workgroup (2 per wave, one after the other); the K x K mean-of-products matrix (fp32: the forms
+// below lose about 50 x 2^-24 of relative accuracy to cancellation, far inside what batch normalisation notices) is
+// staged in LDS with 16-byte loads and read column-wise (it is symmetric), so the lanes of a wave read consecutive words.
+#define GRAM_FIN_CH 8
+template <int K>
+__global__ __launch_bounds__(256) void bn_gram_finalize_kernel(const float* __restrict__ gm, const bf16_t* __restrict__ W, long ldw,
+                                                               int N, float count, const float* __restrict__ weight,
+                                                               const float* __restrict__ bias, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, float* __restrict__ scale,
+                                                               float* __restrict__ shift, float eps, float momentum) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* G = (float*)smem;                        // [K][K]
+    float* mu = G + K * K;                          // [K]
+    float* wv = mu + K;                             // [4 waves][K]
+    constexpr int R = K / 64;                       // rows (= columns) of the matrix per lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {                                               // mu follows G in both layouts; (K*K + K) / 4 float4, several in flight
+        constexpr int NV = (K * K + K) / 4;
+        const f32x4* src = (const f32x4*)gm;
+        f32x4* dst = (f32x4*)G;
+#pragma unroll 8
+        for (int i = threadIdx.x; i < NV; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (int cc = 0; cc < GRAM_FIN_CH / 4; ++cc) {
+        const int c = blockIdx.x * GRAM_FIN_CH + wave * (GRAM_FIN_CH / 4) + cc;
+        if (c >= N) break;                          // wave-uniform
+        float wl[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { wl[r] = (float)W[(long)c * ldw + lane + 64 * r]; wv[wave * K + lane + 64 * r] = wl[r]; }
+        __builtin_amdgcn_wave_barrier();
+        double t[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) t[r] = 0.0;
+        for (int j = 0; j < K; ++j) {
+            const float wj = wv[wave * K + j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) t[r] += (double)(G[j * K + lane + 64 * r] * wj);
+        }
+        double q = 0.0, m = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { q += (double)wl[r] * t[r]; m += (double)wl[r] * (double)mu[lane + 64 * r]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { q += __shfl_xor(q, o, 64); m += __shfl_xor(m, o, 64); }
+        __builtin_amdgcn_wave_barrier();            // every lane has read wv before the next channel overwrites it
+        if (lane == 0) {
+            const float mean = (float)m;
+            const float var = fmaxf((float)(q - m * m), 0.f);
+            const float sc = weight[c] * rsqrtf(var + eps);
+            scale[c] = sc;
+            shift[c] = bias[c] - mean * sc;
+            if (running_mean) {
+                const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+            }
+        }
+    }
+}
+
+extern "C" int64_t avsr_bn_gram_workspace_doubles(int64_t K) { return (K * K + K + 1) / 2; }    // holds K*K + K floats
+
+extern "C" int avsr_bn_gram_finalize(avsr_stream_t stream, const float* gram_parts, const float* colsum_parts, int64_t parts,
+                                     int64_t K, double count, const void* W_bf16, int64_t ldw, int64_t N, const float* weight,
+                                     const float* bias, float* running_mean, float* running_var, float* scale, float* shift,
+                                     float eps, float momentum, double* workspace) {
+    if (!gram_parts || !colsum_parts || !W_bf16 || !weight || !bias || !scale || !shift || !workspace) return AVSR_EINVAL;
+    if (parts <= 0 || N <= 0 || count <= 0 || ldw < K) return AVSR_EINVAL;
+    if (K != 64 && K != 128) return AVSR_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int KK = (int)(K * K);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((KK + K + 63) / 64)), dim3(1024), 0, s, gram_parts, colsum_parts,
+                       (int)parts, KK, (int)K, 1.0 / count, (float*)workspace);
+    const size_t lds = (size_t)(KK + K + 4 * K) * sizeof(float);
+    const dim3 grid((unsigned)((N + GRAM_FIN_CH - 1) / GRAM_FIN_CH));
+    const float* gm = (const float*)workspace;
+    if (K == 64) {
+        hipLaunchKernelGGL(bn_gram_finalize_kernel<64>, grid, dim3(256), lds, s, gm, (const bf16_t*)W_bf16, (long)ldw, (int)N,
+                           (float)count, weight, bias, running_mean, running_var, scale, shift, eps, momentum);
+    } else {
+        static avsr_dev_flags attr_set;
+        if (!avsr_allow_lds((const void*)bn_gram_finalize_kernel<128>, (int)lds, attr_set)) return AVSR_EHIP;
+        hipLaunchKernelGGL(bn_gram_finalize_kernel<128>, grid, dim3(256), lds, s, gm, (const bf16_t*)W_bf16, (long)ldw, (int)N,
+                           (float)count, weight, bias, running_mean, running_var, scale, shift, eps, momentum);
+    }
+    return avsr_launch_status();
+}
+
 extern "C" int64_t avsr_bn_finalize_workspace_floats(int64_t C) { return (int64_t)BN_RED_PARTS * 2 * C; }
 
 extern "C" int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq, int64_t nparts, double count,

@@ -74,6 +74,9 @@ class MoCoVisualFrontend(nn.Module):
         self.MoCoModel = _ResNet50Trunk()
         self.compute_dtype = torch.bfloat16
         self.two_pass_min_bytes = int(os.environ.get("AVSR_TWO_PASS_MIN_BYTES", 1 << 60))   # see _conv_bn
+        # batch statistics of bn3 from the Gram matrix of conv3's input (see run_block); AVSR_GRAM_BN3=0 turns it off
+        self.gram_bn3 = os.environ.get("AVSR_GRAM_BN3", "1") != "0"
+        self.gram_widths = (64,) if os.environ.get("AVSR_GRAM_BN3") == "64" else (64, 128)
         self._packed = None
         self._blocks = list(self.MoCoModel.blocks())
 
@@ -179,6 +182,22 @@ class MoCoVisualFrontend(nn.Module):
                 idt = self._conv_bn(y, e["wd"], 1, e["stride"], 0, blk.downsample[1], relu=False)
         h = self._conv_bn(y, e["w1"], 1, 1, 0, blk.bn1, relu=True)
         h = self._conv_bn(h, e["w2"], 3, e["stride"], 1, blk.bn2, relu=True)
+        width = e["w3"].shape[1]
+        if (self.training and self.gram_bn3 and "wd" not in e and h.dtype == torch.bfloat16 and width in self.gram_widths):
+            # Identity-shortcut blocks of layer1 / layer2 (64 / 128 channels into conv3, whose 256- / 512-channel output
+            # is what the block's HBM traffic consists of): the batch statistics of conv3's output follow from the
+            # 64 x 64 / 128 x 128 Gram matrix of its INPUT (one pass over a tensor a quarter of the output's size), so
+            # conv3 applies bn3, the shortcut and the ReLU in its epilogue and the raw product is never stored or
+            # re-read (per block: one write and one read of the widest tensor less, and no apply pass).
+            bn3 = blk.bn3
+            C = e["w3"].shape[0]
+            rows = h.numel() // width
+            gp, cp = ops.gram_stats(h.view(rows, width))
+            aff = torch.empty((2, C), dtype=torch.float32, device=h.device)
+            ops.bn_gram_finalize(gp, cp, rows, e["w3"], bn3.weight.detach(), bn3.bias.detach(), bn3.running_mean,
+                                 bn3.running_var, aff[0], aff[1], bn3.eps, bn3.momentum)
+            return ops.conv_nhwc(h, e["w3"], 1, 1, 1, 0, scale=aff[0], bias=aff[1], act=ops.ACT_RELU_AFTER_RESIDUAL,
+                                 residual=idt.view(-1, C))
         return self._conv_bn(h, e["w3"], 1, 1, 0, blk.bn3, relu=True, residual=idt, residual_affine=idt_aff)
 
     @torch.no_grad()

@@ -450,6 +450,39 @@ def bn_finalize(col_sum, col_sumsq, count, weight, bias, running_mean, running_v
                                C, eps, momentum, _p(ws), _p(tickets)), "avsr_bn_finalize")
 
 
+def gram_stats(x):
+    """Per-share partial Gram matrices and column sums of x [M, K] bf16 (K = 64 or 128, unit inner stride):
+    (gram_parts fp32 [parts, K, K], colsum_parts fp32 [parts, K]) for bn_gram_finalize."""
+    lib = _lib.load()
+    _need_cuda(x)
+    M, K = x.shape
+    if x.dtype != torch.bfloat16 or x.stride(1) != 1:
+        raise ValueError("gram_stats takes a bf16 [M, K] matrix with unit inner stride")
+    parts = int(lib.avsr_gram_parts(M, K))
+    if parts <= 0:
+        raise _lib.AvsrHipError("gram_stats: K must be 64 or 128")
+    gp = torch.empty((parts, K, K), dtype=torch.float32, device=x.device)
+    cp = torch.empty((parts, K), dtype=torch.float32, device=x.device)
+    check(lib.avsr_gram_stats(_stream(), x.data_ptr(), x.stride(0), M, K, gp.data_ptr(), cp.data_ptr()), "avsr_gram_stats")
+    return gp, cp
+
+
+def bn_gram_finalize(gram_parts, colsum_parts, count, w, weight, bias, running_mean, running_var, scale, shift,
+                     eps=1e-5, momentum=0.1):
+    """Training-mode BN affine (and running-statistics update) of the 1x1 convolution with weight ``w`` (bf16 [N, K])
+    from the input's Gram statistics (gram_stats)."""
+    lib = _lib.load()
+    parts, K = colsum_parts.shape
+    N = w.shape[0]
+    if w.dtype != torch.bfloat16 or w.stride(1) != 1 or w.shape[1] != K:
+        raise ValueError("bn_gram_finalize: w must be bf16 [N, K]")
+    ws = torch.empty(int(lib.avsr_bn_gram_workspace_doubles(K)), dtype=torch.float64, device=w.device)
+    check(lib.avsr_bn_gram_finalize(_stream(), gram_parts.data_ptr(), colsum_parts.data_ptr(), parts, K, float(count),
+                                    w.data_ptr(), w.stride(0), N, weight.data_ptr(), bias.data_ptr(), _p(running_mean),
+                                    _p(running_var), scale.data_ptr(), shift.data_ptr(), eps, momentum, ws.data_ptr()),
+          "avsr_bn_gram_finalize")
+
+
 _BN_TICKETS = {}     # (device, stream) -> int32 ticket counters of the split batch-norm reduction
 
 

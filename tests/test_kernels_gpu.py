@@ -792,3 +792,35 @@ def test_logmel_rejects_bad_arguments(dev):
         ops.logmel_fwd(torch.zeros(1, 16000, device=dev), tables, ops.MEL_WHISPER, n_frames=101)
     with pytest.raises(ValueError):
         ops.logmel_fwd(torch.zeros(16000, device=dev), tables, ops.MEL_WHISPER)
+
+
+@pytest.mark.parametrize("M,K,N", [(5000, 64, 256), (375000, 64, 256), (101400, 128, 512), (77, 128, 512)])
+def test_bn_statistics_from_the_input_gram_matrix(dev, M, K, N):
+    """avsr_gram_stats + avsr_bn_gram_finalize: training-mode BN scale / shift and running statistics of a 1x1
+    convolution's output, computed from the K x K Gram matrix and the column sums of its INPUT, against the
+    statistics of the product itself (fp64 on the same bf16 operands)."""
+    g = torch.Generator().manual_seed(M + K)
+    h = torch.relu(torch.randn(M, K, generator=g) * 0.7 + 0.2).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    gamma, beta = 1.0 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    rm, rv = 0.1 * torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
+    y = h.double() @ w.double().t()
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    want_scale = gamma.double() / torch.sqrt(var + 1e-5)
+    want_shift = beta.double() - mean * want_scale
+    want_rm = 0.9 * rm.double() + 0.1 * mean
+    want_rv = 0.9 * rv.double() + 0.1 * var * (M / (M - 1))
+    hd, wd = h.to(dev), w.to(dev)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    aff = torch.empty(2, N, device=dev)
+    gp, cp = ops.gram_stats(hd)
+    assert gp.shape[1:] == (K, K) and cp.shape == (gp.shape[0], K)
+    ops.bn_gram_finalize(gp, cp, M, wd, gamma.to(dev), beta.to(dev), rmd, rvd, aff[0], aff[1])
+    for got, want, tol in ((aff[0], want_scale, 2e-4), (aff[1], want_shift, 2e-4), (rmd, want_rm, 1e-5), (rvd, want_rv, 1e-4)):
+        err = ((got.double().cpu() - want).abs().max() / want.abs().max().clamp_min(1.0)).item()
+        assert err < tol, err
+    # the shares are added in a fixed order: a second run gives the same bits
+    aff2 = torch.empty(2, N, device=dev)
+    gp2, cp2 = ops.gram_stats(hd)
+    ops.bn_gram_finalize(gp2, cp2, M, wd, gamma.to(dev), beta.to(dev), None, None, aff2[0], aff2[1])
+    assert torch.equal(aff, aff2)
