@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, ATT_OCC) void attn_fwd_mfma_kernel(const bf16_
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint32_t bits[4];
-                    avsr_philox4(seed, avsr_attn_counter(row, tk4, kv0 + 32 * st + 8 * g + 4 * hf), bits);
+                    avsr_rand4(seed, avsr_attn_counter(row, tk4, kv0 + 32 * st + 8 * g + 4 * hf), bits);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         sacc[4 * g + e] = avsr_bits_keep(bits[e], pdrop) ? sacc[4 * g + e] * keep_scale : 0.f;
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint32_t bits[4];
-                if (DROP) avsr_philox4(seed, avsr_attn_counter(row, tk4, kv0 + 32 * st + 8 * g + 4 * hf), bits);
+                if (DROP) avsr_rand4(seed, avsr_attn_counter(row, tk4, kv0 + 32 * st + 8 * g + 4 * hf), bits);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * g + e;

@@ -159,34 +159,32 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 
-// Counter-based random bits (Philox-4x32-10 reduced to one 32-bit draw per
-// counter).  The host-side restatement in tests replays it bit for bit.
-__host__ __device__ __forceinline__ uint32_t avsr_mulhi32(uint32_t a, uint32_t b) {
-    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+// Counter-based random draws for dropout: four 16-bit uniform integers per 64-bit counter, from two 32-bit integer
+// hashes of (seed, counter) - a multiply-add of the counter's low word, then the avalanche xorshift 16, * 0x7feb352d,
+// xorshift 15, * 0x846ca68b, xorshift 16.  About 20 integer instructions per four draws (a Philox-4x32-10 call, which
+// this replaces, costs over a hundred: the dropout attention kernels were bound by it).  The host-side restatement
+// in tests/philox_ref.py replays it bit for bit.
+__host__ __device__ __forceinline__ uint32_t avsr_mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
 }
-__host__ __device__ __forceinline__ void avsr_philox4(uint64_t seed, uint64_t idx, uint32_t out[4]) {
-    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = avsr_mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = avsr_mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+__host__ __device__ __forceinline__ void avsr_rand4(uint64_t seed, uint64_t idx, uint32_t out[4]) {
+    const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+    const uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32);
+    const uint32_t base = s0 + c1 * 0x85EBCA77u;
+    const uint32_t h0 = avsr_mix32((c0 * 0x9E3779B1u + base) ^ s1);
+    const uint32_t h1 = avsr_mix32((c0 * 0xC2B2AE3Du + base) ^ ~s1);
+    out[0] = h0 & 0xFFFFu; out[1] = h0 >> 16; out[2] = h1 & 0xFFFFu; out[3] = h1 >> 16;
 }
-__host__ __device__ __forceinline__ uint32_t avsr_philox(uint64_t seed, uint64_t idx) {
-    uint32_t o[4];
-    avsr_philox4(seed, idx, o);
-    return o[0];
+// keep-decision of one 16-bit draw for dropout probability p: keep iff draw >= floor(65536 p)
+__host__ __device__ __forceinline__ bool avsr_bits_keep(uint32_t draw, float p) {
+    return draw >= (uint32_t)(p * 65536.0f);
 }
-__host__ __device__ __forceinline__ bool avsr_bits_keep(uint32_t bits, float p) {
-    return (float)(bits >> 8) * (1.0f / 16777216.0f) >= p;
-}
-// keep-decision for dropout probability p: keep iff u >= p, u uniform in [0,1)
+// element idx of a flat tensor draws output (idx & 3) of counter idx / 4
 __host__ __device__ __forceinline__ bool avsr_keep(uint64_t seed, uint64_t idx, float p) {
-    return avsr_bits_keep(avsr_philox(seed, idx), p);
+    uint32_t o[4];
+    avsr_rand4(seed, idx >> 2, o);
+    return avsr_bits_keep(o[idx & 3], p);
 }
 // Dropout of attention probabilities.  Element (row, key) of a [rows, Tk] matrix
 // (row = (b*H + h)*Tq + q) draws output (key & 3) of counter row*tk4 + key/4 with
@@ -196,7 +194,7 @@ __host__ __device__ __forceinline__ uint64_t avsr_attn_counter(uint64_t row, int
 }
 __host__ __device__ __forceinline__ bool avsr_attn_keep(uint64_t seed, uint64_t row, int tk4, int key, float p) {
     uint32_t o[4];
-    avsr_philox4(seed, avsr_attn_counter(row, tk4, key), o);
+    avsr_rand4(seed, avsr_attn_counter(row, tk4, key), o);
     return avsr_bits_keep(o[key & 3], p);
 }
 

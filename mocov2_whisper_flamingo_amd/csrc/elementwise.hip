@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ x, 
 }
 
 // out = x + tanh(gate) * drop(y)   (models/gate_cross_attention.py:43,47 with the
-// nn.Dropout of :26 folded in; keep decision = philox(seed, element index)).
+// nn.Dropout of :26 folded in; keep decision = avsr_keep(seed, element index)).
 template <typename T>
 __global__ __launch_bounds__(256) void gated_residual_fwd_kernel(const T* __restrict__ x, const T* __restrict__ y,
                                                                  const float* __restrict__ gate, T* __restrict__ out, long n,
@@ -131,10 +131,12 @@ __global__ __launch_bounds__(256) void gated_residual_bwd_kernel(const T* __rest
         for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride * 8) {
             const vec8 dv = *(const vec8*)(dout + i), yv = *(const vec8*)(y + i);
             vec8 o;
+            uint32_t draws[8];                            // i is a multiple of 8: two generator calls cover the eight
+            if (pdrop > 0.f) { avsr_rand4(seed, (uint64_t)i >> 2, draws); avsr_rand4(seed, ((uint64_t)i >> 2) + 1, draws + 4); }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float d = to_f32<T>(dv[e]);
-                if (pdrop > 0.f) d = avsr_keep(seed, (uint64_t)(i + e), pdrop) ? d * ks : 0.f;
+                if (pdrop > 0.f) d = avsr_bits_keep(draws[e], pdrop) ? d * ks : 0.f;
                 acc += d * to_f32<T>(yv[e]);
                 o[e] = from_f32<T>(g * d);
             }

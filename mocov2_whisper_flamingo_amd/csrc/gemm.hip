@@ -227,6 +227,16 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
             const f32x4 c0 = *(const f32x4*)&Ct[lr * LDT + cg * 8], c1 = *(const f32x4*)&Ct[lr * LDT + cg * 8 + 4];
             float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
             float pv[8], av[8];                 // EXT: the second output's values / the saved GELU inputs
+            uint32_t draws[8];                  // EXT: the eight elements' dropout draws (two generator calls)
+            bool draws_ok = false;
+            if constexpr (EXT) {
+                const uint64_t i0 = (uint64_t)((long)m * p.N + n);
+                if (p.p_drop > 0.f && (i0 & 3) == 0) {
+                    avsr_rand4(run_seed, i0 >> 2, draws);
+                    avsr_rand4(run_seed, (i0 >> 2) + 1, draws + 4);
+                    draws_ok = true;
+                }
+            }
             if constexpr (EXT) {
                 if (p.aux) {
                     const OutT* ap = (const OutT*)p.aux + (long)m * p.ldaux + n;
@@ -255,8 +265,11 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                 else if (ACT == AVSR_ACT_RELU) x = fmaxf(x, 0.f);
                 if constexpr (EXT) {
                     if (p.aux) x *= gelu_erf_grad_fast(av[e]);
-                    if (p.p_drop > 0.f)
-                        x = avsr_keep(run_seed, (uint64_t)((long)m * p.N + n + e), p.p_drop) ? x * (1.0f / (1.0f - p.p_drop)) : 0.f;
+                    if (p.p_drop > 0.f) {
+                        const bool keep = draws_ok ? avsr_bits_keep(draws[e], p.p_drop)
+                                                   : avsr_keep(run_seed, (uint64_t)((long)m * p.N + n + e), p.p_drop);
+                        x = keep ? x * (1.0f / (1.0f - p.p_drop)) : 0.f;
+                    }
                 }
                 v[e] = x;
             }

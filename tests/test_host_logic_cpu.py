@@ -355,3 +355,30 @@ def test_spec_augment_draws_follow_the_reference_order_and_ranges():
     assert ts == [[2952, 2952]] * 2 and fs == [[69, 69]] * 2 and off == [17000] * 2 and snr == [999999.0] * 2
     fs, ts, _, _ = fe.draw(1, 160 * 40, 20000, Recorder())        # 41 frames: no room for a 48-frame band
     assert ts == [[-1, -1]] and fs == [[69, 69]]
+
+
+def test_dropout_generator_statistics():
+    """The integer-hash dropout generator (host restatement of csrc/common.h avsr_rand4): keep rate, and no visible
+    correlation between neighbouring elements, neighbouring rows, the four draws of a counter, or the masks of two
+    consecutive training steps (seeds one SEED_STEP_MUL apart)."""
+    import numpy as np
+    from tests.philox_ref import attn_keep_mask, keep_mask, rand4
+    seed = 0x1234567812345678
+    p = 0.1
+    m = keep_mask(seed, (1 << 20,), p).astype(np.float64)
+    assert abs(m.mean() - 0.9) < 1.5e-3
+    x = m - m.mean()
+    for lag in (1, 2, 3, 4, 8, 512, 513):
+        assert abs((x[:-lag] * x[lag:]).mean() / x.var()) < 5e-3, lag
+    step = AVNet.SEED_STEP_MUL
+    m2 = keep_mask((seed + step) & 0xFFFFFFFFFFFFFFFF, (1 << 20,), p).astype(np.float64)
+    assert abs(((m2 - m2.mean()) * x).mean() / x.var()) < 5e-3
+    a = attn_keep_mask(seed, (2, 8, 75, 75), p).astype(np.float64)
+    assert abs(a.mean() - 0.9) < 3e-3
+    xa = a - a.mean()
+    assert abs((xa[:, :, :-1] * xa[:, :, 1:]).mean() / xa.var()) < 1e-2           # neighbouring query rows
+    assert abs((xa[..., :-1] * xa[..., 1:]).mean() / xa.var()) < 1e-2             # neighbouring keys
+    # the 16-bit draws themselves are uniform: mean and variance of 2^20 draws per output
+    for o in rand4(seed, np.arange(1 << 20, dtype=np.uint64)):
+        u = o.astype(np.float64) / 65536.0
+        assert abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1.0 / 12.0) < 2e-3
