@@ -372,16 +372,17 @@ int avsr_bn_apply(avsr_stream_t stream, int in_dtype, int out_dtype, const void*
  * log-sum-exp, CTC(blank, mean, zero_infinity) on log_softmax(logits) and
  * label-smoothed cross entropy over the first min(T, target_width) frames.
  * targets: int64 [B, ldt]; target_width = targets.shape[1].
- * out3 = {ctc, ce, number of CE targets kept}.  The workspace (size from
+ * out4 = {ctc, ce, number of CE targets kept, ctc + ce (the loss of train.py:165)}.  The workspace (size from
  * avsr_head_loss_workspace_floats) carries lse / alpha / beta to the backward,
  * which writes d(w_ctc*up_ctc[0]*ctc + w_ce*up_ce[0]*ce)/d(logits) (a NULL
- * device scalar counts as 1).
+ * device scalar counts as 1) into rows of pitch lddx >= V and sets the columns [V, lddx) of every row to zero
+ * (the padded contraction length of the input-gradient product).
  * ---------------------------------------------------------------------- */
 int64_t avsr_head_loss_workspace_floats(int64_t B, int64_t T, int64_t target_width);
 int avsr_head_loss_fwd(avsr_stream_t stream, const float* logits, int64_t ld, int64_t B, int64_t T, int64_t V,
                        const int64_t* targets, int64_t ldt, int64_t target_width, const int64_t* input_lengths,
                        const int64_t* target_lengths, float label_smoothing, int64_t ignore_index,
-                       int64_t blank, float* ws, float* out3);
+                       int64_t blank, float* ws, float* out4);
 int avsr_head_loss_bwd(avsr_stream_t stream, int grad_dtype, const float* logits, int64_t ld, int64_t B,
                        int64_t T, int64_t V, const int64_t* targets, int64_t ldt, int64_t target_width,
                        const int64_t* input_lengths, const int64_t* target_lengths, float label_smoothing,
@@ -426,6 +427,9 @@ int avsr_gated_residual_bwd(avsr_stream_t stream, int dtype, const void* dout, c
  * GEMM whose K dimension was split over the batch index (few tiles, very long K: the head's dX) */
 int avsr_sum_parts(avsr_stream_t stream, int out_dtype, const float* parts, int64_t part_stride, int64_t S,
                    const float* bias, int64_t ncol, void* out, int64_t n);
+/* AVNet.make_padding_mask after the clamp of models/av_net.py:96,111-114 in one launch: lengths[b] =
+ * min(lengths[b], T) in place, mask[b, t] = (t >= lengths[b]) as bytes (1 = padded key). */
+int avsr_length_mask(avsr_stream_t stream, int64_t* lengths, int64_t B, int64_t T, uint8_t* mask);
 /* out = a + b + c (c may be NULL)  (models/av_net.py:106) */
 int avsr_add3(avsr_stream_t stream, int dtype, const void* a, const void* b, const void* c, void* out, int64_t n);
 /* out[i] = x[i] + table[i % period]: PositionalEncoding.forward (models/utils.py:21-28) called on its own, x + pe[:, :T]

@@ -114,6 +114,7 @@ SIGNATURES = {
     "avsr_gated_residual_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _u64]),
     "avsr_sum_parts": (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _i64, _vp, _i64]),
     "avsr_cast_rows": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _i64, _i64, _f32]),
+    "avsr_length_mask": (_i32, [_vp, _vp, _i64, _i64, _vp]),
     "avsr_add3": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64]),
     "avsr_add_table": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _i64]),
     "avsr_embed_tokens": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp]),

@@ -269,11 +269,20 @@ class AVNet(nn.Module):
         v_in = vis[:, :min_len].reshape(B * min_len, 2048) if min_len < Tv else vis.reshape(B * Tv, 2048)
         v = Fn.linear(v_in, self.video_proj.weight, self.video_proj.bias, self._cache.get(self.video_proj.weight))
         v = self.video_ln(v, self.pos_enc_video.table(min_len)).view(B, min_len, -1)
-        videoLen.clamp_(max=min_len)                                        # in place, as the reference does
+        # videoLen.clamp_(max=min_len) in place, as the reference does, and make_padding_mask, in one launch
+        if videoLen.dtype == torch.int64 and videoLen.is_contiguous():
+            pad_mask = ops.length_mask(videoLen, min_len)
+        else:
+            videoLen.clamp_(max=min_len)
+            pad_mask = self.make_padding_mask(videoLen, min_len)
+        # a and v feed the fusion's input projections AND the sum below: the sum's backward parks their gradient and
+        # the projections' dX products add it in their epilogues (no separate accumulation kernels)
+        same_dtype = a.dtype == self._cache.dtype and v.dtype == self._cache.dtype
+        skip = Fn.SkipGrad() if (torch.is_grad_enabled() and a.requires_grad and v.requires_grad and same_dtype) else None
         fused = self.fusion_module(a, v, audio_mask=audioMask[:, :min_len] if audioMask is not None else None,
-                                   video_mask=self.make_padding_mask(videoLen, min_len))
+                                   video_mask=pad_mask, _skip=skip)
         d = a.shape[-1]
-        out = Fn.Add3Fn.apply(fused.reshape(B * min_len, d), a.reshape(B * min_len, d), v.reshape(B * min_len, d))
+        out = Fn.Add3Fn.apply(fused.reshape(B * min_len, d), a.reshape(B * min_len, d), v.reshape(B * min_len, d), skip)
         return out, B, min_len
 
     def forward(self, inputBatch, encoded=None):
@@ -300,10 +309,10 @@ class AVNet(nn.Module):
         out, B, T = self._features(inp, encoded)
         lin = self.decoder.linear
         wc, wct = self._cache.get(lin.weight)
-        ctc, ce, logits = Fn.HeadLossFn.apply(out, lin.weight, lin.bias, wc, wct, batch["target_ids"],
-                                              batch["audio_lengths"], batch["target_lengths"].reshape(-1).contiguous(),
-                                              B, T, label_smoothing)
-        return ctc + ce, ctc, ce, logits
+        ctc, ce, logits, total = Fn.HeadLossFn.apply(out, lin.weight, lin.bias, wc, wct, batch["target_ids"],
+                                                     batch["audio_lengths"], batch["target_lengths"].reshape(-1).contiguous(),
+                                                     B, T, label_smoothing)
+        return total, ctc, ce, logits             # total = ctc + ce (train.py:165), summed by the loss kernel
 
     @torch.no_grad()
     def decode_ids(self, logits):

@@ -465,6 +465,24 @@ extern "C" int avsr_sum_parts(avsr_stream_t stream, int out_dtype, const float* 
     return avsr_launch_status();
 }
 
+// lengths[b] = min(lengths[b], T) in place; mask[b, t] = t >= lengths[b].  A thread may read a length before or after
+// thread t = 0 has clamped it: t >= len and t >= min(len, T) agree for every t < T.
+__global__ void length_mask_kernel(int64_t* __restrict__ lengths, int B, int T, uint8_t* __restrict__ mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    const int b = i / T, t = i - b * T;
+    const int64_t len = lengths[b];
+    mask[i] = (uint8_t)(t >= len);
+    if (t == 0 && len > T) lengths[b] = T;
+}
+
+extern "C" int avsr_length_mask(avsr_stream_t stream, int64_t* lengths, int64_t B, int64_t T, uint8_t* mask) {
+    if (!lengths || !mask || B <= 0 || T <= 0 || B * T > 0x7fffffff) return AVSR_EINVAL;
+    hipLaunchKernelGGL(length_mask_kernel, dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lengths,
+                       (int)B, (int)T, mask);
+    return avsr_launch_status();
+}
+
 extern "C" int avsr_sumsq_accumulate(avsr_stream_t stream, const float* x, int64_t n, float* out) {
     if (!x || !out || n <= 0) return AVSR_EINVAL;
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 2048, 2048)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);

@@ -294,8 +294,10 @@ extern "C" int avsr_gemm_tn(avsr_stream_t stream, const void* A, int64_t lda, co
     if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return AVSR_EUNSUPPORTED;
     if (64 * std::max(lda, ldb) * 2 > 0x7fffffffLL) return AVSR_EUNSUPPORTED;       // 32-bit byte offsets inside a stage
     hipStream_t s = (hipStream_t)stream;
-    // thousands of 64 x 64 tiles (the vocabulary head): 128 x 128 tiles halve the operand traffic out of L2
-    if (((N + 63) / 64) * ((K + 63) / 64) >= 2048)
+    // thousands of 64 x 64 tiles (the vocabulary head): 128 x 128 tiles halve the operand traffic out of L2; the same
+    // for contractions over thousands of rows, where the 64 x 64 form (one 32 x 32 block per wave, two fragment reads
+    // per MFMA) is bound by its LDS reads: 146 -> see profiles for the 25 600-row weight gradients
+    if (((N + 63) / 64) * ((K + 63) / 64) >= 2048 || (M >= 4096 && N >= 128 && K >= 128))
         return launch_tn<2, 2>(s, A, lda, B, ldb, C, ldc, M, N, K, accumulate, colsum, accumulate_colsum);
     return launch_tn<1, 3>(s, A, lda, B, ldb, C, ldc, M, N, K, accumulate, colsum, accumulate_colsum);
 }

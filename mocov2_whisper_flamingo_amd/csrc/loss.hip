@@ -145,15 +145,17 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 }
 
 // loss_ctc = mean_b( zero_inf(nll[b]) / max(tg_len[b], 1) )   (reduction='mean')
+// out4 = {ctc, ce, number of CE targets kept, ctc + ce}: the cross-entropy pair was left in `ce` by ce_reduce_kernel
 __global__ void ctc_reduce_kernel(const float* __restrict__ nll, const int64_t* __restrict__ tg_len, int B,
-                                  float* __restrict__ out) {
+                                  const float* __restrict__ ce, float* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) {
             const float v = nll[b];
             if (v != INFINITY && v == v) s += v / (float)max((long)tg_len[b], 1L);
         }
-        out[0] = s / (float)B;
+        const float ctc = s / (float)B;
+        out[0] = ctc; out[1] = ce[0]; out[2] = ce[1]; out[3] = ctc + ce[0];
     }
 }
 
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(256) void head_grad_dense_kernel(const float* __res
         if (v == tg) g -= c1;
         dr[v] = from_f32<TG>(g);
     }
+    for (long v = V + threadIdx.x; v < lddx; v += 256) dr[v] = from_f32<TG>(0.f);      // the row's padding columns
 }
 
 // Sparse CTC term: dx[b,t,l'_s] -= g_ctc * exp(alpha + beta + nll - lp).  Several
@@ -275,8 +278,8 @@ extern "C" int64_t avsr_head_loss_workspace_floats(int64_t B, int64_t T, int64_t
 extern "C" int avsr_head_loss_fwd(avsr_stream_t stream, const float* logits, int64_t ld, int64_t B, int64_t T, int64_t V,
                                   const int64_t* targets, int64_t ldt, int64_t max_target_len, const int64_t* input_lengths,
                                   const int64_t* target_lengths, float label_smoothing, int64_t ignore_index,
-                                  int64_t blank, float* ws, float* out3) {
-    if (!logits || !targets || !input_lengths || !target_lengths || !ws || !out3) return AVSR_EINVAL;
+                                  int64_t blank, float* ws, float* out4) {
+    if (!logits || !targets || !input_lengths || !target_lengths || !ws || !out4) return AVSR_EINVAL;
     if (B <= 0 || T <= 0 || V <= 0 || max_target_len <= 0 || max_target_len > ldt) return AVSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int64_t rows = B * T, Smax = 2 * max_target_len + 1;
@@ -291,9 +294,7 @@ extern "C" int avsr_head_loss_fwd(avsr_stream_t stream, const float* logits, int
     hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3((unsigned)(2 * B)), dim3(256), st_bytes + (in_lds ? tab_bytes : 0), s, logits,
                        (long)ld, lse, targets, (long)ldt, input_lengths, target_lengths, alpha, beta, nll, (int)B, (int)T,
                        (int)Smax, (int)blank, in_lds);
-    hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(64), 0, s, nll, target_lengths, (int)B, out3);
-    // out3 = {ctc, ce, n_ce_targets}: copy ce[0], ce[1] behind the ctc value
-    if (hipMemcpyAsync(out3 + 1, ce, 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_EHIP;
+    hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(64), 0, s, nll, target_lengths, (int)B, ce, out4);
     return avsr_launch_status();
 }
 

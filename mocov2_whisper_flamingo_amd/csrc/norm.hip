@@ -293,6 +293,9 @@ extern "C" int avsr_layernorm_fwd(avsr_stream_t stream, int in_dtype, int out_dt
     return avsr_launch_status();
 }
 
+#ifndef LN_BWD_CAP_TALL
+#define LN_BWD_CAP_TALL 512
+#endif
 extern "C" int avsr_layernorm_bwd(avsr_stream_t stream, int x_dtype, int g_dtype, const void* dy, int64_t lddy,
                                   const void* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                                   void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int64_t D) {
@@ -307,7 +310,9 @@ extern "C" int avsr_layernorm_bwd_res(avsr_stream_t stream, int x_dtype, int g_d
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return AVSR_EINVAL;
     if (D % 4 || D > 64 * 4 * LN_MAXV || ldx % 4 || lddy % 4 || lddx % 4 || (dres && lddr % 4)) return AVSR_EUNSUPPORTED;
     long nb = (rows + 7) / 8;        // ~2 rows per wave; one atomic per column per block at the end
-    const long cap = rows > 8192 ? 1024 : 256;      // tall operands: the row stream, not the atomics, sets the time
+    // every workgroup ends in one atomic per column on the SAME 2 D words: past a few hundred workgroups those
+    // serialise at the memory side (measured at 25 600 rows x 512: 124 us with 1024 workgroups)
+    const long cap = rows > 8192 ? LN_BWD_CAP_TALL : 256;
     if (nb > cap) nb = cap;
     dim3 grid((unsigned)nb), block(256);
     hipStream_t s = (hipStream_t)stream;

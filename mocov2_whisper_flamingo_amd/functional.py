@@ -167,13 +167,17 @@ def _param_grads_here(dy, x, has_bias, pw, pb, rows, parts):
     return dw, db
 
 
-def _dx_gemm(dy, wct):
-    """dX = dY @ W.  Few output tiles with a very long reduction (the vocabulary head: M x 512 over
+def _dx_gemm(dy, wct, extra=None):
+    """dX = dY @ W (+ extra).  Few output tiles with a very long reduction (the vocabulary head: M x 512 over
     K = 52k) would leave the chip idle; split K over 16 batched GEMMs and sum the partials."""
     K = dy.shape[1]
     if K >= 16384 and K % (16 * 64) == 0 and dy.shape[0] * wct.shape[0] <= 1 << 20:
-        return ops.gemm_nt_splitk(dy, wct, 16)
-    return ops.gemm_nt(dy, wct)
+        dx = ops.gemm_nt_splitk(dy, wct, 16)
+        return dx if extra is None else dx + extra
+    if extra is not None and extra.dtype == dy.dtype and extra.is_contiguous() and extra.shape == (dy.shape[0], wct.shape[0]):
+        return ops.gemm_nt(dy, wct, residual=extra)              # the sum rides in the product's epilogue
+    dx = ops.gemm_nt(dy, wct)
+    return dx if extra is None else dx + extra
 
 
 class LinearFn(Function):
@@ -182,11 +186,13 @@ class LinearFn(Function):
     compute-dtype copies the kernels read."""
 
     @staticmethod
-    def forward(ctx, x, w, b, wc, wct, out_dtype, ld_out, sink=None):
+    def forward(ctx, x, w, b, wc, wct, out_dtype, ld_out, sink=None, skip=None):
         """``sink`` = (weight parameter, bias parameter, row range or None, pieces per step): where the
-        parameter gradients may be accumulated directly (see ``grad_sink``)."""
+        parameter gradients may be accumulated directly (see ``grad_sink``).  ``skip`` = (SkipGrad, slot): a
+        gradient that reaches ``x`` along another path and is added to dx inside the dX product (see SkipGrad)."""
         N = wc.shape[0]
         ctx.sink = sink
+        ctx.skip = skip
         if ld_out is None:
             y = ops.gemm_nt(x, wc, bias=b, out_dtype=out_dtype)
         else:   # padded leading dimension: the result is a [M, N] view of a [M, ld_out] buffer
@@ -209,9 +215,10 @@ class LinearFn(Function):
             pad[:, :N].copy_(dy)
             dy = pad[:, :N]
         dyk = dy if Np == N else torch.as_strided(dy, (M, Np), (dy.stride(0), 1))   # padding columns are zero
-        dx = _dx_gemm(dyk, wct) if ctx.needs_input_grad[0] else None
+        extra = ctx.skip[0].take(ctx.skip[1]) if ctx.skip is not None else None
+        dx = _dx_gemm(dyk, wct, extra) if ctx.needs_input_grad[0] else None
         dw, db = _param_grads(dy, x, ctx.has_bias, ctx.sink)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class LayerNormFn(Function):
@@ -350,14 +357,36 @@ class GatedXattnBlockFn(Function):
         return (dx, dxa, None, None, None) + tuple(grads)
 
 
+class SkipGrad:
+    """Gradient of a tensor that feeds a sum AND a linear layer (AVNet: ``out = fused + a + v`` with ``a`` and ``v``
+    also the inputs of the fusion's two projections): instead of autograd adding the two contributions with a kernel
+    of its own, the sum's backward parks its gradient here and the linear layer's dX product adds it in its epilogue.
+    The sum is the last consumer in forward order, so its backward always runs first."""
+
+    def __init__(self):
+        self.slots = {}
+
+    def put(self, slot, grad):
+        self.slots[slot] = grad
+
+    def take(self, slot):
+        return self.slots.pop(slot, None)
+
+
 class Add3Fn(Function):
     @staticmethod
-    def forward(ctx, a, b, c):
+    def forward(ctx, a, b, c, skip=None):
+        """``skip``: a SkipGrad that takes the gradients of ``b`` and ``c`` (slots "b", "c") instead of autograd."""
+        ctx.skip = skip
         return ops.add3(a, b, c)
 
     @staticmethod
     def backward(ctx, d):
-        return d, d, d
+        if ctx.skip is not None:
+            ctx.skip.put("b", d)
+            ctx.skip.put("c", d)
+            return d, None, None, None
+        return d, d, d, None
 
 
 class HeadLossFn(Function):
@@ -379,15 +408,22 @@ class HeadLossFn(Function):
         ctx.save_for_backward(x, wct, buf, ws, targets, input_lengths, target_lengths)
         ctx.cfg = (B, T, V, ld, label_smoothing)
         ctx.mark_non_differentiable(logits)
-        return out3[0], out3[1], logits
+        ctx.set_materialize_grads(False)          # no zero tensors for the outputs nobody differentiates (logits: 124 MB)
+        return out3[0], out3[1], logits, out3[3]
 
     @staticmethod
-    def backward(ctx, g_ctc, g_ce, _g_logits):
+    def backward(ctx, g_ctc, g_ce, _g_logits, g_total):
         x, wct, buf, ws, targets, input_lengths, target_lengths = ctx.saved_tensors
         B, T, V, ld, ls = ctx.cfg
         logits = buf.view(B, T, ld)[:, :, :V]
-        gc = g_ctc.reshape(1).float().contiguous() if g_ctc is not None else torch.zeros(1, device=x.device)
-        ge = g_ce.reshape(1).float().contiguous() if g_ce is not None else torch.zeros(1, device=x.device)
+
+        def upstream(g):          # d(loss)/d(ctc) = its own gradient + the total's; usually only the total's arrives
+            parts = [t.reshape(1).float() for t in (g, g_total) if t is not None]
+            if not parts:
+                return torch.zeros(1, device=x.device)
+            return (parts[0] if len(parts) == 1 else parts[0] + parts[1]).contiguous()
+
+        gc, ge = upstream(g_ctc), upstream(g_ce)
         dl = ops.head_loss_bwd(logits, targets, input_lengths, target_lengths, ws, x.dtype, label_smoothing=ls,
                                up_ctc=gc, up_ce=ge, ld_out=ld)                       # [B*T, ld], pad columns zero
         dx = _dx_gemm(dl, wct)
@@ -395,9 +431,9 @@ class HeadLossFn(Function):
         return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def linear(x, w, b, cache_entry, out_dtype=None, ld_out=None, sink=None):
+def linear(x, w, b, cache_entry, out_dtype=None, ld_out=None, sink=None, skip=None):
     """``w`` / ``b`` parameters (sink defaults to them) or row slices of parameters (pass ``sink``)."""
     wc, wct = cache_entry
     if sink is None and isinstance(w, torch.nn.Parameter):
         sink = (w, b if isinstance(b, torch.nn.Parameter) else None, None, 1)
-    return LinearFn.apply(x, w, b, wc, wct, out_dtype, ld_out, sink)
+    return LinearFn.apply(x, w, b, wc, wct, out_dtype, ld_out, sink, skip)

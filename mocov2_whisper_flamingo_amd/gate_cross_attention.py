@@ -134,18 +134,22 @@ class GatedCrossModalFusion(nn.Module):
             if seed_delta_fn is not None:
                 layer._seed_delta_fn = seed_delta_fn
 
-    def forward(self, audio_features, video_features, audio_mask=None, video_mask=None):
+    def forward(self, audio_features, video_features, audio_mask=None, video_mask=None, _skip=None):
         """``audio_mask`` is accepted and unused, as in the reference
-        (models/gate_cross_attention.py:60-70)."""
+        (models/gate_cross_attention.py:60-70).  ``_skip`` (internal): a functional.SkipGrad whose slots "b" / "c"
+        hold gradients that reach the audio / video features along another path; the two input projections add
+        them inside their dX products."""
         B, T, d = audio_features.shape
         Tk = video_features.shape[1]
         cdt = self._cache.dtype
         a = audio_features if audio_features.dtype == cdt else audio_features.to(cdt)
         v = video_features if video_features.dtype == cdt else video_features.to(cdt)
+        sa = (_skip, "b") if (_skip is not None and a is audio_features) else None
+        sv = (_skip, "c") if (_skip is not None and v is video_features) else None
         x = Fn.linear(a.reshape(B * T, d), self.audio_proj.weight, self.audio_proj.bias,
-                      self._cache.get(self.audio_proj.weight)).view(B, T, d)
+                      self._cache.get(self.audio_proj.weight), skip=sa).view(B, T, d)
         xa = Fn.linear(v.reshape(B * Tk, d), self.video_proj.weight, self.video_proj.bias,
-                       self._cache.get(self.video_proj.weight)).view(B, Tk, d)
+                       self._cache.get(self.video_proj.weight), skip=sv).view(B, Tk, d)
         # xa feeds every block: their backward kernels add into one gradient buffer (see functional.SharedGrad)
         shared = None
         if torch.is_grad_enabled() and xa.requires_grad and all(layer.fused for layer in self.layers):

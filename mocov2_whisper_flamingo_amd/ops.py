@@ -509,7 +509,7 @@ def bn_apply(x, scale, shift, *, residual=None, residual_affine=None, relu=True,
 
 
 def head_loss_fwd(logits, targets, input_lengths, target_lengths, label_smoothing=0.1, ignore_index=-100, blank=0):
-    """logits fp32 [B,T,V] (row stride may exceed V).  Returns (out3, ws): out3 = [ctc, ce, n_ce]."""
+    """logits fp32 [B,T,V] (row stride may exceed V).  Returns (out4, ws): out4 = [ctc, ce, n_ce, ctc + ce]."""
     lib = _lib.load()
     B, T, V = logits.shape
     if logits.dtype != torch.float32 or logits.stride(2) != 1 or logits.stride(0) != T * logits.stride(1):
@@ -517,7 +517,7 @@ def head_loss_fwd(logits, targets, input_lengths, target_lengths, label_smoothin
     Lw = targets.shape[1]
     nws = lib.avsr_head_loss_workspace_floats(B, T, Lw)
     ws = torch.empty(nws, dtype=torch.float32, device=logits.device)
-    out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
+    out3 = torch.empty(4, dtype=torch.float32, device=logits.device)
     check(lib.avsr_head_loss_fwd(_stream(), logits.data_ptr(), logits.stride(1), B, T, V, targets.data_ptr(),
                                  targets.stride(0), Lw, input_lengths.data_ptr(), target_lengths.data_ptr(),
                                  label_smoothing, ignore_index, blank, ws.data_ptr(), out3.data_ptr()), "avsr_head_loss_fwd")
@@ -529,9 +529,7 @@ def head_loss_bwd(logits, targets, input_lengths, target_lengths, ws, grad_dtype
     lib = _lib.load()
     B, T, V = logits.shape
     ld = ld_out or V
-    buf = torch.empty((B * T, ld), dtype=grad_dtype, device=logits.device)
-    if ld > V:
-        buf[:, V:].zero_()
+    buf = torch.empty((B * T, ld), dtype=grad_dtype, device=logits.device)      # the kernel zeroes the columns past V
     check(lib.avsr_head_loss_bwd(_stream(), _DT[grad_dtype], logits.data_ptr(), logits.stride(1), B, T, V,
                                  targets.data_ptr(), targets.stride(0), targets.shape[1], input_lengths.data_ptr(),
                                  target_lengths.data_ptr(), label_smoothing, ignore_index, blank, ws.data_ptr(), w_ctc,
@@ -664,6 +662,19 @@ def gated_residual_bwd(dout, y, gate, dgate, p_drop=0.0, seed=0):
     check(lib.avsr_gated_residual_bwd(_stream(), _dt(dout), dout.data_ptr(), y.data_ptr(), gate.data_ptr(), dy.data_ptr(),
                                       dgate.data_ptr(), dout.numel(), p_drop, seed), "avsr_gated_residual_bwd")
     return dy
+
+
+def length_mask(lengths, T):
+    """lengths int64 [B] is clamped to T IN PLACE (models/av_net.py:96); returns the bool [B, T] padding mask
+    (True = padded, models/av_net.py:111-114)."""
+    lib = _lib.load()
+    _need_cuda(lengths)
+    if lengths.dtype != torch.int64 or not lengths.is_contiguous():
+        raise ValueError("lengths must be a contiguous int64 tensor")
+    B = lengths.numel()
+    mask = torch.empty((B, T), dtype=torch.uint8, device=lengths.device)
+    check(lib.avsr_length_mask(_stream(), lengths.data_ptr(), B, T, mask.data_ptr()), "avsr_length_mask")
+    return mask.view(torch.bool)
 
 
 def add3(a, b, c=None):
