@@ -36,7 +36,7 @@ METRIC = "AV clips/sec (30 s audio+75 video frames) fwd+bwd, Whisper-small"
 MODELARGS = (512, 8, 6, 3000, 2048, 0.1)      # reference config.py:12-17
 VOCAB = 51865
 PEAK_BF16_TFLOPS = 2500.0                      # dense MFMA peak, MI355X
-TRAFFIC_FILE = "r02_pmc_traffic.json"          # HBM counters of the dominant kernel (scripts/pmc_traffic.py)
+TRAFFIC_FILE = "r03_pmc_traffic.json"          # HBM counters of the dominant kernel (scripts/pmc_traffic.py)
 
 
 import contextlib
@@ -426,7 +426,7 @@ def main():
         step()
         torch.cuda.synchronize()
         model.overlap_encoders, Fn.GRAD_STREAM = True, saved
-        recs = [(a.elapsed_time(b) * 1e-3, fl) for a, b, fl, tag, *_rest in ops.GEMM_PROFILE if tag == "bf16"]
+        recs = [(a.elapsed_time(b) * 1e-3, fl, shape[5]) for a, b, fl, tag, shape, *_rest in ops.GEMM_PROFILE if tag == "bf16"]
         ops.GEMM_PROFILE = None
         tsum, fsum = sum(r[0] for r in recs), sum(r[1] for r in recs)
         achieved = fsum / tsum / 1e12
@@ -444,6 +444,7 @@ def main():
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_launches": traffic_launches,
+                    "algorithmic_bytes_per_launch": round(sum(r[2] for r in recs) / len(recs)),
                     "traffic_source": None if traffic is None else
                     f"profiles/{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, committed "
                     "with the code and read back here (not measured by this run)",

@@ -104,8 +104,16 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
     e0.record()
     check(lib.avsr_gemm_nt(_stream(), ctypes.byref(d)), "avsr_gemm_nt")
     e1.record()
+    # algorithmic bytes: each operand read once (a convolution's input image once, not once per tap), the output
+    # written once, the residual read once where the period does not make it a broadcast
+    a_elems = a.numel() if conv is not None else Mv * K * batch
+    nbytes = a.element_size() * (a_elems + N * K * (batch if batched else 1))
+    if out is not None:
+        nbytes += out.element_size() * Mv * N * batch
+        if residual is not None:
+            nbytes += out.element_size() * (res_period if res_period else Mv) * N * batch
     rec = (e0, e1, 2.0 * Mv * N * K * batch, "bf16" if a.dtype == torch.bfloat16 else "f32",
-           (Mv, N, K, batch, None if conv is None else tuple(conv)))
+           (Mv, N, K, batch, None if conv is None else tuple(conv), nbytes))
     if GEMM_PROFILE_REPEAT:        # scripts only: time an immediate second launch of the same product (cache-warm)
         e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e2.record()
