@@ -15,6 +15,7 @@ struct GemmP {
     long lda, ldb, ldc, sA, sB, sC;
     float alpha; const float* scale; const float* bias; int act;
     const void* res; long ldr; int res_period; const float* gate; float* csum; float* csq;
+    int stat_parts;                         // rows of the csum / csq slabs (>= tiles_m; rows past tiles_m are zero-filled)
     int H, W, Cc, KH, KW, stride, pad_h, pad_w, OH, OW;
     int tiles_m, tiles_n, vec_ok;
     // extended epilogue (dense products only): second output, dropout, multiply by gelu'(aux)
@@ -361,6 +362,12 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
             for (int w = 0; w < 4; ++w) { a += red[(w * 2 + 0) * BN_ + t]; b += red[(w * 2 + 1) * BN_ + t]; }
             p.csum[(long)tm * p.N + n0 + t] = a;
             p.csq[(long)tm * p.N + n0 + t] = b;
+            // the slabs are sized for 128-row tiles: with taller tiles the last row of tiles clears the rows nobody owns
+            if (tm == p.tiles_m - 1)
+                for (int r = p.tiles_m; r < p.stat_parts; ++r) {
+                    p.csum[(long)r * p.N + n0 + t] = 0.f;
+                    p.csq[(long)r * p.N + n0 + t] = 0.f;
+                }
         }
     }
 }
@@ -433,6 +440,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][B
 #ifndef G_BM160_NST
 #define G_BM160_NST 2
 #endif
+#ifndef G_ONE160_NST
+#define G_ONE160_NST 3
+#endif
 #ifndef G_SMALL_TILES
 #define G_SMALL_TILES 128
 #endif
@@ -446,6 +456,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else static_assert(N == 0, "unsupported wait count");
@@ -483,7 +495,7 @@ template <int BN_, int G_NST, int CONV, typename OutT, int BM_ = G_BM, bool EXT 
 #define G_OCC1C 4
 #endif
 __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : G_OCC1) : 2)) void gemm_bf16_kernel(GemmP p) {
-    static_assert(BM_ % 32 == 0 && (BM_ == G_BM || !CONV), "row tile: 4 x whole pieces per wave; conv cursors assume 128");
+    static_assert(BM_ % 32 == 0 && (BM_ == G_BM || CONV != 1), "row tile: 4 x whole pieces per wave; the cursor form assumes 128 rows");
     constexpr int MI = BM_ / 32;                              // 16-row sub-tiles per wave (two waves stacked in M)
     constexpr int APIECES = BM_ / 8, BPIECES = BN_ / 8;       // 1-KiB pieces (8 rows x 128 B)
     constexpr int STAGE_BYTES = (APIECES + BPIECES) * 1024;
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : 
         const int r = (NAL * wave + q) * 8 + (lane >> 3);
         if constexpr (CONV == 2) {
             const ConvRow cr = conv_row(p, m0 + r);
-            const int ko = (q & 1) ? kofs[1] : kofs[0];
+            const int ko = ((NAL * wave + q) & 1) ? kofs[1] : kofs[0];
             pixoff[q] = ((cr.base + cr.ih0 * p.W + cr.iw0) * p.Cc + ko) * (int)sizeof(bf16_t);
             unsigned bits = 0;
             for (int t2 = 0, a = 0; a < p.KH; ++a)
@@ -893,6 +905,21 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         if (bm == G_BM && t160 > G_NUM_CU && fill(t160, 160, p.M, tn) > G_FILL_RATIO * fill(t128, 128, p.M, tn)) bm = 160;
 #endif
     }
+    // One round instead of two: a grid of a little more than one 128-row tile per CU (M = 9600, N = 512, the layer4
+    // convolutions: 300 tiles) makes 44 CUs run two tiles while the rest wait; 240 tiles of 160 rows run one per CU,
+    // behind a three-stage ring.  Dense products and scalar-tap convolutions, with or without column statistics.
+    // Measured on the five such launches of the visual trunk: -28 us together (128 x 64 tiles instead: -18 us; a lone
+    // workgroup per CU runs at a fifth of the CU's matrix rate either way, which is what bounds these launches).
+    bool one_round160 = false;
+#ifndef G_NO_ONE_ROUND160
+    if (bf && bn == 128 && !p.ext && g->batch == 1 && !small) {
+        const long tn = (p.N + 127) / 128;
+        const long t128 = ((p.M + 127) / 128) * tn, t160 = ((p.M + 159) / 160) * tn;
+        const bool fast_ok = conv && g->conv.C % G_BK == 0 && g->conv.KH * g->conv.KW <= 32 &&
+                             (g->M / ((int64_t)g->conv.OH * g->conv.OW)) * g->conv.H * g->conv.W * g->conv.C * 2 < (1ll << 31);
+        if (t128 > G_NUM_CU && t160 <= G_NUM_CU && p.K >= 8 * G_BK && (!conv || fast_ok)) { one_round160 = true; bm = 160; }
+    }
+#endif
     // 256-row tiles (a wave owns 128 x 64: a quarter less LDS traffic per MFMA) pay off only where the tile
     // count stays far above the CU count: +8 % on 4096^3 and larger, a loss on every product of this network.
     if (bf && !conv && !g->col_sum && bn == 128 && g->batch == 1 && bm == G_BM && !p.ext &&
@@ -900,6 +927,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     const int tmS = bf ? bm : FM, tnS = bf ? bn : FN;
     p.tiles_m = (p.M + tmS - 1) / tmS;
     p.tiles_n = (p.N + tnS - 1) / tnS;
+    p.stat_parts = (int)std::max<int64_t>(p.tiles_m, bf ? (p.M + G_BM - 1) / G_BM : 0);
     const long ntiles = (long)p.tiles_m * p.tiles_n;
     if (ntiles > 0x7fffffff || g->batch > 65535) return AVSR_EUNSUPPORTED;
     dim3 grid((unsigned)ntiles, 1, (unsigned)g->batch), block(256);
@@ -919,6 +947,14 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         static avsr_dev_flags attr_set;                                                                        \
         constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV, BMV>();                                            \
         auto kfn = gemm_bf16_kernel<BNV, NSTV, 0, OT, BMV>;                                                \
+        if (!avsr_allow_lds((const void*)kfn, lds_bytes, attr_set)) return AVSR_EHIP;                          \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
+    } while (0)
+#define LAUNCHBMC(BNV, NSTV, OT, BMV)                                                                          \
+    do {                                                                                                       \
+        static avsr_dev_flags attr_set;                                                                        \
+        constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV, BMV>();                                            \
+        auto kfn = gemm_bf16_kernel<BNV, NSTV, 2, OT, BMV>;                                                    \
         if (!avsr_allow_lds((const void*)kfn, lds_bytes, attr_set)) return AVSR_EHIP;                          \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
     } while (0)
@@ -954,6 +990,9 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
             if (of) LAUNCHBM(64, 4, float, 64); else LAUNCHBM(64, 4, bf16_t, 64);
         } else if (bm == 256) {
             if (of) LAUNCHBM(128, 1, float, 256); else LAUNCHBM(128, 1, bf16_t, 256);
+        } else if (one_round160) {                 // one workgroup per CU: a deeper ring hides the DMA latency
+            if (conv) { if (of) LAUNCHBMC(128, G_ONE160_NST, float, 160); else LAUNCHBMC(128, G_ONE160_NST, bf16_t, 160); }
+            else      { if (of) LAUNCHBM(128, G_ONE160_NST, float, 160); else LAUNCHBM(128, G_ONE160_NST, bf16_t, 160); }
         } else if (bm == 160) {
             if (of) LAUNCHBM(128, G_BM160_NST, float, 160); else LAUNCHBM(128, G_BM160_NST, bf16_t, 160);
         } else if (bm == 96) {
@@ -969,6 +1008,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
 #undef LAUNCH
 #undef LAUNCHB
 #undef LAUNCHBM
+#undef LAUNCHBMC
 #undef LAUNCHX
 #undef LAUNCH_CV_OT
 #undef LAUNCH_FAST_OT

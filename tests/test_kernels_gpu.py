@@ -154,6 +154,42 @@ def test_conv_implicit_gemm(dev, dtype, cfg):
     assert rel_err(out, ref) < tol(dtype)
 
 
+@pytest.mark.parametrize("cfg", [
+    # n, H, W, C, Cout, KH, KW, stride, pad: 9600 output rows x 512 channels = 300 tiles of 128 rows, 240 of 160
+    (600, 4, 4, 64, 512, 3, 3, 1, 1),
+    (600, 7, 7, 64, 512, 3, 3, 2, 1),
+    (600, 4, 4, 512, 512, 1, 1, 1, 0),
+    (601, 4, 4, 64, 512, 3, 3, 1, 1),      # 9616 rows: the last 160-row tile is ragged
+])
+def test_conv_one_round_of_tall_tiles_with_statistics(dev, cfg):
+    """Grids of slightly more than one 128-row tile per CU run 160-row tiles; the statistics slabs keep their
+    128-row-tile height, the rows no tile owns must come back as zeros (they are poisoned here)."""
+    n, H, W, C, Co, KH, KW, s, p = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = rnd(g, n, C, H, W, dtype=torch.bfloat16)
+    w = rnd(g, Co, C, KH, KW, dtype=torch.bfloat16, scale=1.0 / math.sqrt(C * KH * KW))
+    scale = torch.rand(Co, generator=g) + 0.5
+    raw = F.conv2d(x, w, None, stride=s, padding=p).permute(0, 2, 3, 1)
+    M = raw.numel() // Co
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev, torch.bfloat16)
+    wd = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous().to(dev, torch.bfloat16)
+    cs = ops.gemm_stats_slabs(M, Co, torch.bfloat16, dev)
+    cs.fill_(float("nan"))
+    out = ops.conv_nhwc(xd, wd, KH, KW, s, p, out_dtype=torch.bfloat16, col_stats=(cs[0], cs[1]))
+    assert rel_err(out, raw) < tol(torch.bfloat16)
+    tot = cs.sum(1)
+    assert torch.isfinite(tot).all()
+    flat = raw.reshape(M, Co)
+    assert rel_err(tot[0], flat.sum(0)) < 1e-3
+    assert rel_err(tot[1], (flat * flat).sum(0)) < 1e-3
+    # with a residual and the ReLU behind it (the identity blocks' last convolution)
+    res = rnd(g, M, Co, dtype=torch.bfloat16)
+    out = ops.conv_nhwc(xd, wd, KH, KW, s, p, out_dtype=torch.bfloat16, scale=scale.to(dev),
+                        act=ops.ACT_RELU_AFTER_RESIDUAL, residual=res.to(dev, torch.bfloat16).view(out.shape))
+    ref = F.relu(flat * scale + res).view(raw.shape)
+    assert rel_err(out, ref) < tol(torch.bfloat16)
+
+
 @pytest.mark.parametrize("idt,odt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
                                      (torch.bfloat16, torch.bfloat16)])
 @pytest.mark.parametrize("D", [384, 512, 768, 1024, 1280])
