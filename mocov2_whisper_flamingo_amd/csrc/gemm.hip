@@ -920,10 +920,16 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         if (t128 > G_NUM_CU && t160 <= G_NUM_CU && p.K >= 8 * G_BK && (!conv || fast_ok)) { one_round160 = true; bm = 160; }
     }
 #endif
-    // 256-row tiles (a wave owns 128 x 64: a quarter less LDS traffic per MFMA) pay off only where the tile
-    // count stays far above the CU count: +8 % on 4096^3 and larger, a loss on every product of this network.
+    // 256-row tiles (a wave owns 128 x 64: a quarter less LDS traffic per MFMA) pay off where K is long and there are
+    // at least two such tiles per CU: 4096^3 918 -> 1140 TFLOP/s, 8192^3 1066 -> 1161; a loss on every product of this
+    // network (M = 12000, K = 768: 846 tiles on 512 resident slots, and prologue + epilogue of a 12-step tile weigh more).
     if (bf && !conv && !g->col_sum && bn == 128 && g->batch == 1 && bm == G_BM && !p.ext &&
-        ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 2 * G_NST_SWITCH_TILES && p.K >= 2048) bm = 256;
+        ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 2 * G_NUM_CU && p.K >= 2048) bm = 256;
+#ifdef G_TUNE_ENV
+    if (bf && !conv && !g->col_sum && bn == 128 && !p.ext && !small) {          // tuning builds only
+        if (const char* e = getenv("AVSR_FORCE_BM")) { bm = atoi(e); one_round160 = false; }
+    }
+#endif
     const int tmS = bf ? bm : FM, tnS = bf ? bn : FN;
     p.tiles_m = (p.M + tmS - 1) / tmS;
     p.tiles_n = (p.N + tnS - 1) / tnS;

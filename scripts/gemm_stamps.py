@@ -8,7 +8,7 @@ lib = ctypes.CDLL(os.path.abspath('scripts/variants/libavsr_stamps.so'))
 lib.avsr_gemm_nt.restype = ctypes.c_int
 lib.avsr_gemm_nt.argtypes = [ctypes.c_void_p, ctypes.POINTER(GemmDesc)]
 lib.avsr_debug_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
-for M, N, K in [(128, 128, 64), (128, 128, 512), (600, 512, 512), (600, 512, 2048), (12000, 768, 768)]:
+for M, N, K in [(128, 128, 768), (12000, 2304, 768), (12000, 3072, 768), (12000, 768, 3072), (4096, 4096, 4096)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16); b = torch.randn(N, K, device=dev).to(torch.bfloat16)
     for odt in (torch.bfloat16, torch.float32):
         out = torch.empty(M, N, device=dev, dtype=odt)

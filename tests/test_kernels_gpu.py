@@ -540,6 +540,23 @@ def test_bn_finalize_slabs(dev, nparts, C):
     assert all(int(t.abs().sum()) == 0 for t in ops._BN_TICKETS.values())
 
 
+@pytest.mark.parametrize("shape", [(3, 50, 50, 64), (2, 13, 17, 128), (1, 7, 9, 256), (2, 5, 70, 64), (2, 24, 24, 8)])
+def test_maxpool_bf16_bands(dev, shape):
+    """The 16-byte bf16 max-pool (bands of output rows, the shared input row carried in registers): odd sizes,
+    more output columns than one pass covers, negative scales, with and without the fused affine + ReLU."""
+    n, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = rnd(g, n, H, W, C, dtype=torch.bfloat16)
+    sc, sh = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.3
+    xd = x.to(dev, torch.bfloat16)
+    ref = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    out = ops.maxpool3x3s2(xd)
+    assert out.shape == ref.shape and torch.equal(out.float().cpu(), ref)
+    ref = F.max_pool2d(F.relu(x * sc + sh).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    out = ops.maxpool3x3s2(xd, scale=sc.to(dev), shift=sh.to(dev))
+    assert rel_err(out, ref) < tol(torch.bfloat16)
+
+
 @pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
 def test_stem_pool_bn(dev, odt):
     g = torch.Generator().manual_seed(5)
