@@ -86,6 +86,7 @@ class AVNet(nn.Module):
         self._side = None
         self._aside = None
         self._graphs = {}
+        self.max_encoder_graphs = 3             # live encoder recordings (train / validation / test shapes)
         self._seed_delta = None             # device record of a graphed training step (dp.GraphedTail), else None
         self.fusion_module.set_runtime(self._cache, self._dropout_seed, lambda: self._seed_delta)
         if device is not None:
@@ -204,7 +205,10 @@ class AVNet(nn.Module):
                 cur = torch.cuda.current_stream()
                 for side, ev in out["done"]:                                 # join the visual stream into the capture
                     cur.wait_event(ev)
-        return (g, st_in, out["enc"], out["vis"])
+        # the recorded kernels read the packed weight copies of this moment: the recording keeps them alive, so a later
+        # re-pack (another module mode) cannot hand their memory to someone else
+        keep = (self.visual_model._packed, self.whisper_model.encoder._packed)
+        return (g, st_in, out["enc"], out["vis"], keep)
 
     def _encode_graph(self, inputBatch, ahead):
         audioBatch, _, videoBatch, _, videoLen = inputBatch
@@ -212,7 +216,9 @@ class AVNet(nn.Module):
                self.prune_unread_frames,
                self.visual_model.training, self.compute_dtype, self.long_form, self.whisper_model.encoder.attn_fp8,
                sum(p._version for p in self.whisper_model.encoder.parameters()),
-               sum(p._version for p in self.visual_model.parameters()), torch.cuda.current_device())
+               sum(p._version for p in self.visual_model.parameters()), torch.cuda.current_device(),
+               # eval mode folds the running statistics into the recording: it is only as fresh as they are
+               None if self.visual_model.training else self.visual_model.stats_version())
         main = torch.cuda.current_stream()
         stream = self._audio_stream
         rec = self._graphs.get(key)
@@ -222,11 +228,18 @@ class AVNet(nn.Module):
             except RuntimeError as e:       # e.g. a runtime that refuses the capture: keep working, launch by launch
                 logger.warning("HIP graph capture of the frozen encoders failed (%s); launching them eagerly", e)
                 rec = False
-            self._graphs.clear()                                                 # one live recording: its pool is large
+            # a recording's pool holds every encoder activation (a few GB): keep the most recent few, so a loop that
+            # alternates training and validation (another module mode, often another batch shape) re-records neither
+            while len(self._graphs) >= max(1, self.max_encoder_graphs):
+                self._graphs.pop(next(iter(self._graphs)))
             self._graphs[key] = rec
+        else:
+            self._graphs[key] = self._graphs.pop(key)                            # most recently used last
         if rec is False:
             return self.encode(inputBatch, ahead=ahead)
-        g, st_in, enc_s, vis_s = rec
+        g, st_in, enc_s, vis_s, _keep = rec
+        if self.visual_model.training:
+            self.visual_model._stats_epoch += 1                                  # the replay updates the running statistics
         stream.wait_stream(main)                                                 # the inputs are ready on `main`
         with torch.cuda.stream(stream):
             for dst, src in zip(st_in, inputBatch):

@@ -78,12 +78,18 @@ class MoCoVisualFrontend(nn.Module):
         self.gram_bn3 = os.environ.get("AVSR_GRAM_BN3", "1") != "0"
         self.gram_widths = (64,) if os.environ.get("AVSR_GRAM_BN3") == "64" else (64, 128)
         self._packed = None
+        self._stats_epoch = 0                   # bumped by every batch-statistics forward (the kernels write the buffers raw)
         self._blocks = list(self.MoCoModel.blocks())
+
+    def stats_version(self):
+        """Changes whenever the BN running statistics may have: a training-mode forward (here or replayed from a
+        recording) or an in-place write by the caller (load_state_dict, copy_)."""
+        return (self._stats_epoch, sum(b._version for b in self.buffers()))
 
     # ---- weight packing -------------------------------------------------
     def _pack(self, dtype):
         key = (dtype, self.training, sum(p._version for p in self.parameters()),
-               0 if self.training else sum(b._version for b in self.buffers()), next(self.parameters()).data_ptr())
+               None if self.training else self.stats_version(), next(self.parameters()).data_ptr())
         if self._packed is not None and self._packed[0] == key:
             return self._packed[1]
 
@@ -213,6 +219,7 @@ class MoCoVisualFrontend(nn.Module):
         for i in range(len(self._blocks)):
             y = self.run_block(i, y, pk)
         if self.training:   # one fused increment for all 54 counters
+            self._stats_epoch += 1
             torch._foreach_add_([m.num_batches_tracked for m in self.modules()
                                  if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d))], 1)
         return ops.avgpool_mask(y, x_len, B, T, self.compute_dtype)

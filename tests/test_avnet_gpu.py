@@ -292,6 +292,42 @@ def test_encoders_issued_ahead_and_from_a_graph(dev, training):
                         encoded=m.encode(m.batch_inputs(batches[1])))
 
 
+def test_encoder_recordings_survive_a_mode_switch(dev):
+    """Training and validation alternate (train.py:143-201): the training-mode recording survives a validation phase
+    and is replayed afterwards instead of being recorded again; an eval-mode recording has the running statistics
+    folded in, so it is reused only while they have not moved; the oldest recording is dropped past the limit."""
+    m, _ = _micro_avnet(torch.bfloat16, dev, p_drop=0.0)
+    batch = to_device(synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=41), dev)
+    inp = lambda: m.batch_inputs(dict(batch, video_lengths=batch["video_lengths"].clone()))
+    seen = {}
+    for mode in (True, False, True, False):
+        m.train(mode)
+        stats = [b.clone() for b in m.visual_model.buffers()]
+        ref = m.encode(inp())
+        for b, saved in zip(m.visual_model.buffers(), stats):       # the eager pass must not count as a step
+            b.copy_(saved)
+        got = m.encode(inp(), graph=True)
+        torch.cuda.synchronize()
+        assert torch.equal(got["enc"], ref["enc"]) and torch.equal(got["vis"], ref["vis"])
+        key = next(reversed(m._graphs))
+        if mode and mode in seen:
+            assert m._graphs[key][0] is seen[mode]                  # the recording of the first visit, replayed
+        if not mode:
+            if mode in seen:                                        # a training pass moved the statistics since
+                assert m._graphs[key][0] is not seen[mode]
+            again = m.encode(inp(), graph=True)                     # nothing moved: the same recording serves
+            torch.cuda.synchronize()
+            assert next(reversed(m._graphs)) == key and torch.equal(again["vis"], ref["vis"])
+        seen[mode] = m._graphs[key][0]
+    assert len(m._graphs) == 3
+    m.max_encoder_graphs = 1
+    m.train(True)
+    m.prune_unread_frames = False                                   # a third key
+    m.encode(inp(), graph=True)
+    torch.cuda.synchronize()
+    assert len(m._graphs) == 1
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_avnet_forward_and_training_step(dev, dtype):
     m, sd = _micro_avnet(dtype, dev)
