@@ -560,6 +560,15 @@ __global__ __launch_bounds__(256) void avgpool_mask_bf16x8_kernel(const bf16_t* 
         const bf16_t* xp = x + ((long)frame * HW * C8 + cg) * 8;
         const long step = (long)C8 * 8;
         int p = 0;
+        for (; p + 16 <= HW; p += 16) {         // the trunk's last stage is 4 x 4 pixels: all sixteen loads in flight
+            bf16x8 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = *(const bf16x8*)(xp + (p + u) * step);
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (float)v[u][e];
+        }
         for (; p + 4 <= HW; p += 4) {
             bf16x8 v[4];
 #pragma unroll
