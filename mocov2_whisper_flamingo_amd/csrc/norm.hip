@@ -293,6 +293,9 @@ extern "C" int avsr_layernorm_fwd(avsr_stream_t stream, int in_dtype, int out_dt
     return avsr_launch_status();
 }
 
+#ifndef LN_BWD_CAP_SHORT
+#define LN_BWD_CAP_SHORT 64
+#endif
 #ifndef LN_BWD_CAP_TALL
 #define LN_BWD_CAP_TALL 512
 #endif
@@ -310,9 +313,9 @@ extern "C" int avsr_layernorm_bwd_res(avsr_stream_t stream, int x_dtype, int g_d
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return AVSR_EINVAL;
     if (D % 4 || D > 64 * 4 * LN_MAXV || ldx % 4 || lddy % 4 || lddx % 4 || (dres && lddr % 4)) return AVSR_EUNSUPPORTED;
     long nb = (rows + 7) / 8;        // ~2 rows per wave; one atomic per column per block at the end
-    // every workgroup ends in one atomic per column on the SAME 2 D words: past a few hundred workgroups those
-    // serialise at the memory side (measured at 25 600 rows x 512: 124 us with 1024 workgroups)
-    const long cap = rows > 8192 ? LN_BWD_CAP_TALL : 256;
+    // every workgroup ends in one atomic per column on the SAME 2 D words, and those serialise at the memory side
+    // (25 600 rows x 512: 124 us with 1024 workgroups; 3200 rows: 41 us with 256, 22 us with 64; 600 rows: 13.5 / 11.8 us)
+    const long cap = rows > 8192 ? LN_BWD_CAP_TALL : LN_BWD_CAP_SHORT;
     if (nb > cap) nb = cap;
     dim3 grid((unsigned)nb), block(256);
     hipStream_t s = (hipStream_t)stream;
