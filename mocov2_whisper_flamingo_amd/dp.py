@@ -34,6 +34,9 @@ from . import ops
 
 # Debug switch: hand gloo the device tensors themselves when ranks share a GPU (see FlatTrainer._reduce_bucket).
 GLOO_DEVICE_TENSORS = os.environ.get("AVSR_GLOO_DEVICE_TENSORS", "0") == "1"
+# matrices from this many elements on are overwritten by their gradient kernel instead of cleared and accumulated into
+# (FlatTrainer.overwrite); AVSR_OVERWRITE_GRAD=0 turns that off
+OVERWRITE_MIN_ELEMS = (1 << 22) if os.environ.get("AVSR_OVERWRITE_GRAD", "1") != "0" else (1 << 62)
 
 
 def trainable_parameters(model):
@@ -130,6 +133,30 @@ class FlatTrainer:
         if pending:
             self.buckets.append({"range": (start, total), "params": pending, "left": 0})
         self._bucket_of = {id(p): b for b in self.buckets for p in b["params"]}
+        # Large matrices whose gradient is produced by ONE kernel per step and whose module says so (the vocabulary
+        # head, utils.Decoder: 26.5 M of the 38 M elements) need neither the optimizer's clearing write nor the producer's read of the cleared buffer: in the
+        # fused mode without accumulation the producer OVERWRITES their range (functional._param_grads_here reads the
+        # flag) and the optimizer leaves it as it is - 8 bytes per element and step less.  Their .grad then holds the
+        # last step's gradient, not zeros, between step() and the next backward; a step in which the producer did
+        # not run clears the range before the norm is taken.
+        self.overwrite = []
+        if self.fused_step and self.accumulate == 1 and self.shard is None and self.on_gpu:
+            single = {id(q) for m in model.modules() if hasattr(m, "single_kernel_gradients")
+                      for q in m.single_kernel_gradients()}
+            for (n, p), o, s in zip(order, offs, sizes):
+                if s >= OVERWRITE_MIN_ELEMS and id(p) in single:
+                    p._avsr_overwrite_grad = True
+                    p._avsr_grad_written = False
+                    self.overwrite.append((p, o, (s + 3) // 4 * 4))
+        # optimizer segments: (lo, hi, clear the gradient after use)
+        self._segments, pos = [], 0
+        for _, o, s in sorted(self.overwrite, key=lambda e: e[1]):
+            if o > pos:
+                self._segments.append((pos, o, True))
+            self._segments.append((o, o + s, False))
+            pos = o + s
+        if pos < total:
+            self._segments.append((pos, total, True))
         self.overlap = overlap and self.collective
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.on_gpu and self.overlap) else None
         self._works = []
@@ -317,6 +344,14 @@ class FlatTrainer:
             torch.cuda.current_stream().wait_stream(self.grad_stream)
 
     # ---- optimizer ----------------------------------------------------------
+    def _settle_overwritten(self):
+        """A range its producer overwrites holds the previous step's gradient until then: if the producer did not
+        run in this step (the loss did not reach the parameter), the gradient is zero - make it so."""
+        for p, o, s in self.overwrite:
+            if not p._avsr_grad_written:
+                self.flat_grad[o:o + s].zero_()
+            p._avsr_grad_written = False
+
     def step(self, lr=None):
         """Global-norm clip (train.py:321) + AdamW (train.py:219-225) on the flat buffers."""
         self.join_gradients()
@@ -324,12 +359,14 @@ class FlatTrainer:
         lr = self.lr if lr is None else lr
         scr = self._scratch
         scr.zero_()
+        self._settle_overwritten()
         if self.shard is None:
             ops.sumsq_accumulate(self.flat_grad, scr[0:1])
             ops.clip_scale(scr[0:1], self.max_norm, scr[1:2], scr[2:3], pre_scale=self._pre_scale)
-            ops.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, lr=lr,
-                           betas=self.betas, eps=self.eps, weight_decay=self.wd, grad_scale=scr[1:2],
-                           clear_grad=self.fused_step)
+            for lo, hi, clear in self._segments:
+                ops.adamw_step(self.flat_param[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                               self.step_count, lr=lr, betas=self.betas, eps=self.eps, weight_decay=self.wd,
+                               grad_scale=scr[1:2], clear_grad=self.fused_step and clear)
             self._clean = self.fused_step
         else:
             # the norm of the whole gradient = the shards' sums of squares added up (4 bytes over the links)
@@ -424,8 +461,10 @@ class GraphedTail:
         scr = tr._scratch                    # [sum of squares (zero on entry), clip factor, norm]
         ops.sumsq_accumulate(tr.flat_grad, scr[0:1])
         ops.clip_scale(scr[0:1], tr.max_norm, scr[1:2], scr[2:3], pre_scale=1.0 / tr.world)
-        ops.adamw_step_dev(tr.flat_param, tr.flat_grad, tr.exp_avg, tr.exp_avg_sq, record, betas=tr.betas, eps=tr.eps,
-                           weight_decay=tr.wd, grad_scale=scr[1:2], clear_grad=True, reset=scr[0:1])
+        for i, (lo, hi, clear) in enumerate(tr._segments):
+            ops.adamw_step_dev(tr.flat_param[lo:hi], tr.flat_grad[lo:hi], tr.exp_avg[lo:hi], tr.exp_avg_sq[lo:hi], record,
+                               betas=tr.betas, eps=tr.eps, weight_decay=tr.wd, grad_scale=scr[1:2], clear_grad=clear,
+                               reset=scr[0:1] if i == len(tr._segments) - 1 else None)
         self.model._cache.refresh_inplace()
 
     def _eager(self, batch, encoded, lr):

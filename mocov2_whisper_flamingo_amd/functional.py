@@ -136,8 +136,13 @@ def _param_grads_here(dy, x, has_bias, pw, pb, rows, parts):
         if has_bias and gb is None:
             db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device)
         if gw is not None:
-            ops.gemm_tn(dy, x, out=gw, accumulate=True, colsum=gb if gb is not None else db,
+            # a parameter whose owner promises ONE gradient kernel per step (dp.FlatTrainer.overwrite) is written, not
+            # read-added-written: the buffer then needs no clearing either
+            over = rows is None and parts == 1 and getattr(pw, "_avsr_overwrite_grad", False)
+            ops.gemm_tn(dy, x, out=gw, accumulate=not over, colsum=gb if gb is not None else db,
                         accumulate_colsum=gb is not None)
+            if over:
+                pw._avsr_grad_written = True
             dw = None
             grad_done(pw, parts)
         else:
@@ -149,7 +154,10 @@ def _param_grads_here(dy, x, has_bias, pw, pb, rows, parts):
     xt = ops.transpose2d(x, pad_to=8)                       # [K, Mp]
     gw = grad_sink(pw, rows)
     if gw is not None:
-        ops.gemm_nt(dyt, xt, out=gw, residual=gw)
+        over = rows is None and parts == 1 and getattr(pw, "_avsr_overwrite_grad", False)
+        ops.gemm_nt(dyt, xt, out=gw, residual=None if over else gw)
+        if over:
+            pw._avsr_grad_written = True
         dw = None
     else:
         dw = ops.gemm_nt(dyt, xt, out_dtype=torch.float32)  # [N, K]

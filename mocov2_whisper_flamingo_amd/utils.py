@@ -59,6 +59,12 @@ class Decoder(nn.Module):
         self.linear = nn.Linear(d_model, vocab_size)
         self._cache = Fn.WeightCache(dtype)         # AVNet replaces it with the cache it shares with the fusion
 
+    def single_kernel_gradients(self):
+        """Parameters whose gradient comes from ONE kernel launch per backward pass (LinearFn's weight-gradient product):
+        a gradient-buffer owner may let that kernel overwrite the buffer instead of accumulating into a cleared one
+        (dp.FlatTrainer.overwrite)."""
+        return [self.linear.weight]
+
     def forward(self, x):
         """x [B, T, d_model] (or [rows, d_model]) on the GPU -> fp32 logits [B, T, vocab] (models/utils.py:36-44).
         The logits live in a buffer whose row stride is padded; the returned tensor is a view of it."""

@@ -702,3 +702,42 @@ def test_flat_trainer_fused_step_matches_plain(dev):
     assert abs(na - nb) <= 1e-5 * na
     # fp32 atomics order the dW partial sums differently from run to run: equal to rounding, not bit for bit
     assert float((trs[0].flat_param - trs[1].flat_param).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_gradient_overwrite_mode_follows_the_clearing_trajectory(dev, graphed, monkeypatch):
+    """FlatTrainer(fused_step=True) lets the weight-gradient kernel of a large matrix overwrite its range of the flat
+    gradient buffer instead of accumulating into a cleared one (the vocabulary head from 4 M elements on; here from 1024).  Same losses, same updates as the clearing mode over five steps, eager and replayed from
+    the recorded graphs - and a step without any backward pass treats the stale ranges as zero gradients."""
+    import copy
+    from mocov2_whisper_flamingo_amd import dp
+    m0, _ = _micro_avnet(torch.bfloat16, dev, p_drop=0.0)
+    m0.train()
+    batches = [to_device(synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=70 + s), dev) for s in range(5)]
+    runs = []
+    for min_elems in (1 << 62, 1024):
+        monkeypatch.setattr(dp, "OVERWRITE_MIN_ELEMS", min_elems)
+        m = copy.deepcopy(m0)
+        tr = dp.FlatTrainer(m, lr=1e-3, bucket_mb=0.25, overlap=False, grad_stream=False, fused_step=True)
+        assert [p is m.decoder.linear.weight for p, _, _ in tr.overwrite] == ([True] if min_elems == 1024 else [])
+        assert sum(hi - lo for lo, hi, _ in tr._segments) == tr.flat_grad.numel()
+        tail = dp.GraphedTail(tr, warmup=2 if graphed else 10 ** 9)
+        losses = []
+        for b0 in batches:
+            b = dict(b0, video_lengths=b0["video_lengths"].clone())
+            losses.append(tail.step(b, m.encode(m.batch_inputs(b)))[0].detach().clone())
+        if not graphed:                 # a step no backward pass fed: zero gradients everywhere, stale ranges included
+            tr.zero_grad()
+            tr.step()
+        torch.cuda.synchronize()
+        assert tail.failed is None and (tail.rec is not None) == graphed
+        runs.append((losses, {k: p.detach().clone() for k, p in m.named_parameters()}))
+    (l0, p0), (l1, p1) = runs
+    for a, b in zip(l0, l1):
+        assert abs(a.item() - b.item()) <= 2e-3 * abs(a.item())
+    start = dict(m0.named_parameters())
+    for k, _ in dp.trainable_parameters(m0):
+        u0, u1 = (p0[k] - start[k]).float().reshape(-1), (p1[k] - start[k]).float().reshape(-1)
+        if u0.numel() >= 1024:
+            assert abs(u1.norm().item() / u0.norm().item() - 1.0) <= 2e-2, k
+            assert torch.dot(u0, u1).item() >= 0.98 * u0.norm().item() * u1.norm().item(), k
