@@ -166,7 +166,8 @@ int avsr_attn_fwd(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, 
  * The split is only offered on the full 256-CU / 8-XCD device the workgroup-id mapping was measured on (all shares
  * of an item have equal blockIdx & 7, i.e. share one XCD's L2 under round-robin placement; the shares themselves
  * travel by system-scope stores and loads, so the sum does not depend on that placement): on any other device or
- * CU partition avsr_attn_fwd_workspace_bytes returns 0 and the call runs unsplit.  The current device must be the
+ * CU partition avsr_attn_fwd_workspace_bytes returns 0 and the call runs unsplit, and so does a call on a stream
+ * created with a CU mask (hipExtStreamCreateWithCUMask), whatever the workspace.  The current device must be the
  * stream's device. */
 int64_t avsr_attn_fwd_workspace_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk, float p_drop, int causal);
 int avsr_attn_fwd_ws(avsr_stream_t stream, int dtype, int use_mfma, const void* Q, int64_t ldq, const void* K,

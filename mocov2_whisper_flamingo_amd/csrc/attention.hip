@@ -1102,6 +1102,16 @@ struct AttnSplit { int whole, rest, nsplit; };
 // blockIdx & 7, i.e. (under the round-robin placement of workgroups over 8 XCDs) the same XCD and L2.  The shares are
 // exchanged with system-scope stores and loads, which go through to memory on any placement; the plan below is only
 // offered on the 256-CU / 8-XCD layout the id mapping was measured on, any other device or partition runs unsplit.
+// A stream created with a CU mask places workgroups on a subset of the CUs: ids with equal blockIdx & 7 need not share
+// an XCD then, so such a stream runs unsplit.
+static bool stream_sees_every_cu(hipStream_t s) {
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};              // 256 CUs
+    if (hipExtStreamGetCUMask(s, 8, mask) != hipSuccess) { (void)hipGetLastError(); return false; }
+    for (int i = 0; i < 8; ++i)
+        if (mask[i] != 0xffffffffu) return false;
+    return true;
+}
+
 static AttnSplit attn_split_plan(int64_t B, int64_t H, int64_t Tq, int64_t Tk, int causal, bool dropout) {
     const int per_xcd = (int)((B * H + 7) / 8), qtiles = (int)((Tq + 127) / 128), items = per_xcd * qtiles;
     AttnSplit pl{items, 0, 1};
@@ -1171,7 +1181,7 @@ extern "C" int avsr_attn_fwd_sd(avsr_stream_t stream, int dtype, int use_mfma, c
         AttnSplit pl = attn_split_plan(B, H, Tq, Tk, causal, p_drop > 0.f);
         float* part_ws = nullptr;
         int* tickets = nullptr;
-        if (pl.nsplit >= 2 && workspace && ((uintptr_t)workspace % 256) == 0 &&
+        if (pl.nsplit >= 2 && workspace && ((uintptr_t)workspace % 256) == 0 && stream_sees_every_cu(s) &&
             workspace_bytes >= avsr_attn_fwd_workspace_bytes(B, H, Tq, Tk, p_drop, causal)) {
             tickets = (int*)workspace;
             part_ws = (float*)((char*)workspace + ((8LL * pl.rest * 4 + 255) / 256) * 256);

@@ -322,6 +322,36 @@ def test_attn_fwd_split_last_round(dev, B, H, Tq, Tk, masked, p):
         assert o1[1].abs().max() == 0
 
 
+def test_attn_fwd_split_not_taken_on_a_cu_masked_stream(dev):
+    """The key split relies on workgroups with equal (id & 7) sharing an XCD; a stream restricted to part of the CUs
+    (hipExtStreamCreateWithCUMask) gives no such placement, so the forward must run unsplit there: bit-identical
+    to the call without a workspace, and the workspace's tickets stay untouched."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (ctypes.c_uint32 * 8)(*([0xffffffff] * 4 + [0] * 4))          # the lower half of the CUs
+    sp = ctypes.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(sp), 8, words) == 0
+    stream = torch.cuda.ExternalStream(sp.value)
+    B, H, Tq, Tk = 4, 6, 500, 500
+    g = torch.Generator().manual_seed(5)
+    q = rnd(g, B, Tq, H * 64).to(dev, torch.bfloat16)
+    kv = rnd(g, B, Tk, 2 * H * 64).to(dev, torch.bfloat16)
+    kw = dict(scale=0.125, use_mfma=True, save_lse=True)
+    o0, l0 = ops.attn_fwd(q, kv[:, :, :H * 64], kv[:, :, H * 64:], H, **kw)
+    ws = ops.AttnWorkspace()
+    ops.attn_fwd(q, kv[:, :, :H * 64], kv[:, :, H * 64:], H, workspace=ws, **kw)      # allocates and zeroes it
+    torch.cuda.synchronize()
+    ws._buf.fill_(0x5A)                            # a split launch would spin on (or trip over) these tickets
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        o1, l1 = ops.attn_fwd(q, kv[:, :, :H * 64], kv[:, :, H * 64:], H, workspace=ws, **kw)
+    stream.synchronize()
+    assert torch.equal(o1, o0) and torch.equal(l1, l0)
+    assert int((ws._buf != 0x5A).sum()) == 0
+    ws._buf.zero_()
+    assert hip.hipStreamDestroy(sp) == 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("p", [0.0, 0.25])
 def test_attn_valu_fwd_bwd(dev, dtype, p):
