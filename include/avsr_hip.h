@@ -96,6 +96,12 @@ typedef struct {
     /* optional device word added to `seed` when the kernel runs (NULL = none): lets a launch recorded in a HIP
      * graph draw a different dropout mask on every replay (see avsr_step_params) */
     const uint64_t* seed_delta;
+    /* optional (bf16 inputs, act NONE, dense, batch 1): per row and 128-column tile of the product, the partial
+     * log-sum-exp statistics of the values `pre` would hold - row_part[(tile * M + m) * 4 + {0, 1, 2}] = {max, sum of
+     * exp(v - max), sum of v} over the tile's valid columns, tile = n / 128, ceil(N / 128) tiles.  Lets the consumer of a
+     * very wide product (the vocabulary head) get every row's log-sum-exp without reading the product back:
+     * avsr_head_loss_fwd(..., row_part, n_parts). */
+    float* row_part;
 } avsr_gemm_t;
 
 int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g);
@@ -378,12 +384,15 @@ int avsr_bn_apply(avsr_stream_t stream, int in_dtype, int out_dtype, const void*
  * which writes d(w_ctc*up_ctc[0]*ctc + w_ce*up_ce[0]*ce)/d(logits) (a NULL
  * device scalar counts as 1) into rows of pitch lddx >= V and sets the columns [V, lddx) of every row to zero
  * (the padded contraction length of the input-gradient product).
+ * row_part / n_parts (optional, NULL / 0 = off): the per-tile log-sum-exp partials the product that made the logits
+ * wrote (avsr_gemm_t.row_part, n_parts = ceil(V / 128)); the forward then merges them instead of reading the
+ * logits row by row (it still gathers the target columns the two losses need).
  * ---------------------------------------------------------------------- */
 int64_t avsr_head_loss_workspace_floats(int64_t B, int64_t T, int64_t target_width);
 int avsr_head_loss_fwd(avsr_stream_t stream, const float* logits, int64_t ld, int64_t B, int64_t T, int64_t V,
                        const int64_t* targets, int64_t ldt, int64_t target_width, const int64_t* input_lengths,
                        const int64_t* target_lengths, float label_smoothing, int64_t ignore_index,
-                       int64_t blank, float* ws, float* out4);
+                       int64_t blank, float* ws, float* out4, const float* row_part, int64_t n_parts);
 int avsr_head_loss_bwd(avsr_stream_t stream, int grad_dtype, const float* logits, int64_t ld, int64_t B,
                        int64_t T, int64_t V, const int64_t* targets, int64_t ldt, int64_t target_width,
                        const int64_t* input_lengths, const int64_t* target_lengths, float label_smoothing,

@@ -30,7 +30,7 @@ class GemmDesc(_c.Structure):
         ("residual", _vp), ("ldr", _i64), ("res_period", _i64), ("gate", _vp),
         ("col_sum", _vp), ("col_sumsq", _vp), ("conv", ConvDesc),
         ("pre", _vp), ("ldp", _i64), ("mul_gelu_grad_of", _vp), ("ld_aux", _i64), ("p_drop", _f32), ("seed", _u64),
-        ("seed_delta", _vp),
+        ("seed_delta", _vp), ("row_part", _vp),
     ]
 
 
@@ -101,7 +101,7 @@ SIGNATURES = {
     "avsr_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32]),
     "avsr_bn_apply": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32]),
     "avsr_head_loss_workspace_floats": (_i64, [_i64, _i64, _i64]),
-    "avsr_head_loss_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _i64, _i64, _vp, _vp]),
+    "avsr_head_loss_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp, _i64]),
     "avsr_head_loss_bwd": (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _i64, _i64,
                                   _vp, _f32, _f32, _vp, _vp, _vp, _i64]),
     "avsr_argmax_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp]),

@@ -67,6 +67,13 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += AVSR_DPP(v, 0x140);
     return v;
 }
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, AVSR_DPP(v, 0xB1));
+    v = fmaxf(v, AVSR_DPP(v, 0x4E));
+    v = fmaxf(v, AVSR_DPP(v, 0x141));
+    v = fmaxf(v, AVSR_DPP(v, 0x140));
+    return v;
+}
 // v + v[lane ^ O] for O = 8 (rotate the row by 8), 16 and 32 (lane-swap instructions): exact partners, no LDS
 template <int O> __device__ __forceinline__ float xor_add(float v) {
     static_assert(O == 8 || O == 16 || O == 32, "xor_add: 8, 16 or 32");

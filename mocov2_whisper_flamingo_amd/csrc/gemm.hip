@@ -21,6 +21,7 @@ struct GemmP {
     // extended epilogue (dense products only): second output, dropout, multiply by gelu'(aux)
     void* pre; long ldp; const void* aux; long ldaux; float p_drop; unsigned long long seed; int ext;
     const unsigned long long* seed_delta;
+    float* row_part;                        // [tiles of 128 columns][M][4]: per-row {max, sum exp, sum} of a tile (EXT)
 };
 
 // Block id -> (tile_m, tile_n).  Blocks are dealt round-robin over the 8 XCDs;
@@ -273,6 +274,23 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                     }
                 }
                 v[e] = x;
+            }
+            if constexpr (EXT && BN_ == 128) {
+                if (p.row_part) {               // log-sum-exp partials of this row over the tile's valid columns
+                    float mx = -INFINITY, sx = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < p.N) { mx = fmaxf(mx, pv[e]); sx += pv[e]; }
+                    mx = row16_max(mx);         // the 16 lanes of a row hold its 128 columns
+                    float se = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < p.N) se += __expf(pv[e] - mx);
+                    se = row16_sum(se);
+                    sx = row16_sum(sx);
+                    if (cg == 0)
+                        *(f32x4*)(p.row_part + ((long)(n0 / BN_) * p.M + m) * 4) = (f32x4){mx, se, sx, 0.f};
+                }
             }
             if constexpr (EXT) {
                 if (p.pre) {
@@ -862,7 +880,9 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     p.stride = g->conv.stride; p.pad_h = g->conv.pad_h; p.pad_w = g->conv.pad_w; p.OH = g->conv.OH; p.OW = g->conv.OW;
     p.pre = g->pre; p.ldp = g->ldp; p.aux = g->mul_gelu_grad_of; p.ldaux = g->ld_aux;
     p.p_drop = g->p_drop; p.seed = g->seed; p.seed_delta = (const unsigned long long*)g->seed_delta;
-    p.ext = (g->pre || g->mul_gelu_grad_of || g->p_drop > 0.f || !g->C) ? 1 : 0;
+    p.row_part = g->row_part;
+    if (g->row_part && (!bf || g->act != AVSR_ACT_NONE || !aligned_to(g->row_part, 16))) return AVSR_EUNSUPPORTED;
+    p.ext = (g->pre || g->mul_gelu_grad_of || g->p_drop > 0.f || !g->C || g->row_part) ? 1 : 0;
     if (p.ext) {
         const size_t osz_ = g->out_dtype == AVSR_BF16 ? 2 : 4;
         if ((!g->pre || (aligned_to(g->pre, 16) && (g->ldp * osz_) % 16 == 0)) &&
@@ -881,7 +901,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     int bn = (bf && g->N <= 64 && !p.ext) ? 64 : 128;
     // A grid of a few dozen 128 x 128 tiles leaves most CUs idle while each busy one grinds through its tile's whole
     // K loop at one CU's MFMA rate: 64 x 64 tiles put four times as many CUs to work on a quarter of the tile each.
-    const bool small = bf && !conv && !g->col_sum && g->batch == 1 && bn == 128 &&
+    const bool small = bf && !conv && !g->col_sum && g->batch == 1 && bn == 128 && !g->row_part &&     // row_part: 128-wide tiles
                        ((g->M + 127) / 128) * ((g->N + 127) / 128) <= G_SMALL_TILES;
     if (small) bn = 64;
     // Row tile: 128, or 96 where that fills the CUs' last round much better (M = 12000, N = 768: 564 tiles leave a

@@ -33,6 +33,25 @@ __global__ __launch_bounds__(1024) void row_lse_kernel(const float* __restrict__
     if (threadIdx.x == 0) { lse[blockIdx.x] = mx + __logf(s); if (sumx) sumx[blockIdx.x] = sx; }
 }
 
+// The same two row quantities from per-tile partials {max, sum of exp(v - max), sum of v} that the product which made the
+// logits left behind (part[(tile * rows + row) * 4 + ..]): a wave per row, no pass over the logits.
+__global__ __launch_bounds__(256) void row_lse_merge_kernel(const float* __restrict__ part, int nparts, int rows,
+                                                            float* __restrict__ lse, float* __restrict__ sumx) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float m = -INFINITY, s = 0.f, sx = 0.f;
+    for (int t = lane; t < nparts; t += 64) {
+        const f32x4 a = *(const f32x4*)(part + ((long)t * rows + row) * 4);
+        if (a[0] > m) { s *= __expf(m - a[0]); m = a[0]; }
+        s += a[1] * __expf(a[0] - m);
+        sx += a[2];
+    }
+    const float mx = wave_max(m);
+    s = wave_sum(m == -INFINITY ? 0.f : s * __expf(m - mx));
+    sx = wave_sum(sx);
+    if (lane == 0) { lse[row] = mx + __logf(s); if (sumx) sumx[row] = sx; }
+}
+
 // Label-smoothed CE, mean over non-ignored targets (train.py:103-128).  Rows are
 // (b, t) with t < t_ce; target of row (b,t) is targets[b*ldt + t].  One block.
 // out[0] = loss, out[1] = number of non-ignored targets.
@@ -278,15 +297,20 @@ extern "C" int64_t avsr_head_loss_workspace_floats(int64_t B, int64_t T, int64_t
 extern "C" int avsr_head_loss_fwd(avsr_stream_t stream, const float* logits, int64_t ld, int64_t B, int64_t T, int64_t V,
                                   const int64_t* targets, int64_t ldt, int64_t max_target_len, const int64_t* input_lengths,
                                   const int64_t* target_lengths, float label_smoothing, int64_t ignore_index,
-                                  int64_t blank, float* ws, float* out4) {
+                                  int64_t blank, float* ws, float* out4, const float* row_part, int64_t n_parts) {
     if (!logits || !targets || !input_lengths || !target_lengths || !ws || !out4) return AVSR_EINVAL;
     if (B <= 0 || T <= 0 || V <= 0 || max_target_len <= 0 || max_target_len > ldt) return AVSR_EINVAL;
+    if (row_part && (n_parts != (V + 127) / 128 || (uintptr_t)row_part % 16)) return AVSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int64_t rows = B * T, Smax = 2 * max_target_len + 1;
     float* lse = ws; float* sumx = lse + rows; float* nll = sumx + rows; float* ce = nll + B;
     float* alpha = ce + 2; float* beta = alpha + rows * Smax;
     const int t_ce = (int)(T < max_target_len ? T : max_target_len);
-    hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)rows), dim3(1024), 0, s, logits, (long)ld, (int)V, lse, sumx);
+    if (row_part)
+        hipLaunchKernelGGL(row_lse_merge_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, row_part, (int)n_parts,
+                           (int)rows, lse, sumx);
+    else
+        hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)rows), dim3(1024), 0, s, logits, (long)ld, (int)V, lse, sumx);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, logits, (long)ld, (int)V, lse, sumx, targets, (long)ldt,
                        (int)B, (int)T, t_ce, label_smoothing, (int)ignore_index, ce);
     const size_t tab_bytes = (size_t)T * Smax * sizeof(float), st_bytes = 2 * (size_t)Smax * sizeof(float);

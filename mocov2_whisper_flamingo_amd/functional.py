@@ -6,6 +6,8 @@ and its losses).  Forward and backward both run in the HIP kernels behind
 All activations are 2-D ``[rows, features]`` (or ``[B, T, features]`` for
 attention) tensors of the compute dtype; parameter gradients are fp32.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -397,6 +399,11 @@ class Add3Fn(Function):
         return d, d, d, None
 
 
+# Off by default: at the benchmark's head (600 x 51865 x 512) the partials cost the product's epilogue 26 us and save the
+# loss kernels 31 us - nothing in the step (same-box A/B 7.48 vs 7.48 ms).  AVSR_HEAD_LSE_FROM_PRODUCT=1 turns it on.
+HEAD_LSE_FROM_PRODUCT = os.environ.get("AVSR_HEAD_LSE_FROM_PRODUCT", "0") == "1"
+
+
 class HeadLossFn(Function):
     """Vocabulary head + CTC + label-smoothed CE in one node (models/utils.py:40 and
     train.py:95-128).  Returns (ctc, ce, logits); the logits output is a
@@ -410,9 +417,14 @@ class HeadLossFn(Function):
         ctx.sink = (w, b, None, 1)
         ld = wct.shape[1]
         buf = torch.empty((B * T, ld), dtype=torch.float32, device=x.device)
-        ops.gemm_nt(x, wc, bias=b, out=buf[:, :V])
+        # optional (bf16): the product's epilogue leaves every row's log-sum-exp partials per 128-column tile, so the
+        # loss kernels never stream the 124 MB of logits in the forward
+        part = None
+        if HEAD_LSE_FROM_PRODUCT and x.dtype == torch.bfloat16:
+            part = torch.empty((ops.row_lse_parts(V), B * T, 4), dtype=torch.float32, device=x.device)
+        ops.gemm_nt(x, wc, bias=b, out=buf[:, :V], row_part=part)
         logits = buf.view(B, T, ld)[:, :, :V]
-        out3, ws = ops.head_loss_fwd(logits, targets, input_lengths, target_lengths, label_smoothing)
+        out3, ws = ops.head_loss_fwd(logits, targets, input_lengths, target_lengths, label_smoothing, row_part=part)
         ctx.save_for_backward(x, wct, buf, ws, targets, input_lengths, target_lengths)
         ctx.cfg = (B, T, V, ld, label_smoothing)
         ctx.mark_non_differentiable(logits)

@@ -41,7 +41,7 @@ def _need_cuda(*ts):
 
 
 def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NONE, residual=None,
-            res_period=0, gate=None, alpha=1.0, col_stats=None, conv=None, M=None, stats_only=False):
+            res_period=0, gate=None, alpha=1.0, col_stats=None, conv=None, M=None, stats_only=False, row_part=None):
     """out[m,n] = epi(sum_k a[m,k] b[n,k]).  a: [M,K] or [batch,M,K]; b: [N,K] or [batch,N,K].
     conv = (H, W, C, KH, KW, stride, pad_h, pad_w, OH, OW): a is an NHWC image batch, M = n_img*OH*OW.
     ``stats_only``: fill ``col_stats`` and store no product (returns None)."""
@@ -97,6 +97,10 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
     d.gate = _p(gate)
     if col_stats is not None:
         d.col_sum, d.col_sumsq = col_stats[0].data_ptr(), col_stats[1].data_ptr()
+    if row_part is not None:        # [ceil(N/128), M, 4] fp32: per row and 128-column tile {max, sum exp, sum}
+        if row_part.dtype != torch.float32 or not row_part.is_contiguous() or row_part.numel() < row_lse_parts(N) * Mv * 4:
+            raise ValueError("row_part must be a contiguous fp32 buffer of row_lse_parts(N) * M * 4 floats")
+        d.row_part = row_part.data_ptr()
     if GEMM_PROFILE is None:
         check(lib.avsr_gemm_nt(_stream(), ctypes.byref(d)), "avsr_gemm_nt")
         return out
@@ -516,8 +520,16 @@ def bn_apply(x, scale, shift, *, residual=None, residual_affine=None, relu=True,
     return y
 
 
-def head_loss_fwd(logits, targets, input_lengths, target_lengths, label_smoothing=0.1, ignore_index=-100, blank=0):
-    """logits fp32 [B,T,V] (row stride may exceed V).  Returns (out4, ws): out4 = [ctc, ce, n_ce, ctc + ce]."""
+def row_lse_parts(N):
+    """Column tiles of the per-row log-sum-exp partials a product with N columns writes (gemm_nt(row_part=...))."""
+    return (N + 127) // 128
+
+
+def head_loss_fwd(logits, targets, input_lengths, target_lengths, label_smoothing=0.1, ignore_index=-100, blank=0,
+                  row_part=None):
+    """logits fp32 [B,T,V] (row stride may exceed V).  Returns (out4, ws): out4 = [ctc, ce, n_ce, ctc + ce].
+    ``row_part``: the log-sum-exp partials the product that made the logits wrote (gemm_nt(row_part=...)); the
+    forward then does not read the logits row by row."""
     lib = _lib.load()
     B, T, V = logits.shape
     if logits.dtype != torch.float32 or logits.stride(2) != 1 or logits.stride(0) != T * logits.stride(1):
@@ -528,7 +540,8 @@ def head_loss_fwd(logits, targets, input_lengths, target_lengths, label_smoothin
     out3 = torch.empty(4, dtype=torch.float32, device=logits.device)
     check(lib.avsr_head_loss_fwd(_stream(), logits.data_ptr(), logits.stride(1), B, T, V, targets.data_ptr(),
                                  targets.stride(0), Lw, input_lengths.data_ptr(), target_lengths.data_ptr(),
-                                 label_smoothing, ignore_index, blank, ws.data_ptr(), out3.data_ptr()), "avsr_head_loss_fwd")
+                                 label_smoothing, ignore_index, blank, ws.data_ptr(), out3.data_ptr(), _p(row_part),
+                                 0 if row_part is None else row_lse_parts(V)), "avsr_head_loss_fwd")
     return out3, ws
 
 

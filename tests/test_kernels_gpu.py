@@ -666,6 +666,43 @@ def test_head_loss(dev, T, V, L, ld):
     assert torch.equal(am.cpu(), logits.argmax(-1))
 
 
+@pytest.mark.parametrize("M,V,K", [(600, 1000, 128), (77, 5000, 64), (600, 51865, 512), (10, 129, 64)])
+def test_head_losses_from_the_products_row_partials(dev, M, V, K):
+    """The head product leaves {max, sum exp, sum} per row and 128-column tile (gemm_nt(row_part=...)); merged, they
+    are the row log-sum-exp and row sum the losses need, so the forward never streams the logits: same losses, same
+    workspace rows as the pass over the logits, including a ragged last tile and grids of very few tiles."""
+    g = torch.Generator().manual_seed(M + V)
+    B, T = (8, M // 8) if M % 8 == 0 else (1, M)
+    x = rnd(g, M, K, dtype=torch.bfloat16).to(dev, torch.bfloat16)
+    w = (rnd(g, V, K, dtype=torch.bfloat16) * (4.0 / math.sqrt(K))).to(dev, torch.bfloat16)
+    b = torch.randn(V, generator=g).to(dev)
+    ld = (V + 31) // 32 * 32
+    buf = torch.empty(M, ld, device=dev)
+    part = torch.full((ops.row_lse_parts(V), M, 4), float("nan"), device=dev)
+    ops.gemm_nt(x, w, bias=b, out=buf[:, :V], row_part=part)
+    plain = torch.empty(M, ld, device=dev)
+    ops.gemm_nt(x, w, bias=b, out=plain[:, :V])
+    assert torch.equal(buf[:, :V], plain[:, :V])                   # the product itself is untouched
+    logits = buf[:, :V]
+    tiles = list(logits.split(128, dim=1))
+    ref_max = torch.stack([t.max(1).values for t in tiles])
+    ref_se = torch.stack([(t - t.max(1, keepdim=True).values).exp().sum(1) for t in tiles])
+    ref_sx = torch.stack([t.sum(1) for t in tiles])
+    assert torch.equal(part[..., 0], ref_max)
+    assert rel_err(part[..., 1], ref_se) < 1e-5 and rel_err(part[..., 2], ref_sx) < 1e-5
+    L = 5
+    targets = torch.randint(1, V, (B, L), generator=g).to(dev)
+    il, tl = torch.full((B,), T, device=dev), torch.full((B,), min(L, max(1, T // 3)), device=dev)
+    lg = buf.view(B, T, ld)[:, :, :V]
+    o0, ws0 = ops.head_loss_fwd(lg, targets, il, tl)
+    o1, ws1 = ops.head_loss_fwd(lg, targets, il, tl, row_part=part)
+    assert rel_err(o1, o0) < 1e-5
+    assert rel_err(ws1[:2 * M], ws0[:2 * M]) < 1e-5                 # lse and row sums
+    d0 = ops.head_loss_bwd(lg, targets, il, tl, ws0, torch.float32, ld_out=ld)
+    d1 = ops.head_loss_bwd(lg, targets, il, tl, ws1, torch.float32, ld_out=ld)
+    assert rel_err(d1, d0) < 5e-4                                  # exp(logit - lse): the merge order shows in the last bits
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_elementwise(dev, dtype):
     g = torch.Generator().manual_seed(1)
