@@ -77,6 +77,7 @@ class MoCoVisualFrontend(nn.Module):
         # batch statistics of bn3 from the Gram matrix of conv3's input (see run_block); AVSR_GRAM_BN3=0 turns it off
         self.gram_bn3 = os.environ.get("AVSR_GRAM_BN3", "1") != "0"
         self.gram_widths = (64,) if os.environ.get("AVSR_GRAM_BN3") == "64" else (64, 128)
+        self.gram_downsample = os.environ.get("AVSR_GRAM_DS", "1") != "0"      # layer1.0's shortcut BN the same way
         self._packed = None
         self._stats_epoch = 0                   # bumped by every batch-statistics forward (the kernels write the buffers raw)
         self._blocks = list(self.MoCoModel.blocks())
@@ -180,7 +181,23 @@ class MoCoVisualFrontend(nn.Module):
         e = pk["blocks"][index]
         blk = self._blocks[index]
         idt, idt_aff = y, None
-        if "wd" in e:
+        gram_ds = False
+        if ("wd" in e and self.training and self.gram_bn3 and self.gram_downsample and e["stride"] == 1 and y.dtype == torch.bfloat16
+                and y.shape[-1] in self.gram_widths and e["w3"].shape[1] in self.gram_widths):
+            # layer1's first block: its 1 x 1 shortcut convolution reads the 64-channel block input at stride 1, so
+            # the shortcut BN's batch statistics follow from the Gram matrix of that input as bn3's do from conv3's -
+            # the shortcut is stored normalised, conv3 adds it in its epilogue, and neither raw 256-channel tensor
+            # nor the three-stream apply pass over them exists
+            gram_ds = True
+            bnd = blk.downsample[1]
+            Cin, C = y.shape[-1], e["wd"].shape[0]
+            rows = y.numel() // Cin
+            gp, cp = ops.gram_stats(y.view(rows, Cin))
+            affd = torch.empty((2, C), dtype=torch.float32, device=y.device)
+            ops.bn_gram_finalize(gp, cp, rows, e["wd"], bnd.weight.detach(), bnd.bias.detach(), bnd.running_mean,
+                                 bnd.running_var, affd[0], affd[1], bnd.eps, bnd.momentum)
+            idt = ops.conv_nhwc(y, e["wd"], 1, 1, 1, 0, scale=affd[0], bias=affd[1])
+        elif "wd" in e:
             # batch statistics: the downsample BN has no activation, so its apply pass is folded into bn3's
             if self.training:
                 idt, idt_aff = self._conv_bn(y, e["wd"], 1, e["stride"], 0, blk.downsample[1], relu=False, defer=True)
@@ -189,7 +206,8 @@ class MoCoVisualFrontend(nn.Module):
         h = self._conv_bn(y, e["w1"], 1, 1, 0, blk.bn1, relu=True)
         h = self._conv_bn(h, e["w2"], 3, e["stride"], 1, blk.bn2, relu=True)
         width = e["w3"].shape[1]
-        if (self.training and self.gram_bn3 and "wd" not in e and h.dtype == torch.bfloat16 and width in self.gram_widths):
+        if (self.training and self.gram_bn3 and ("wd" not in e or gram_ds) and h.dtype == torch.bfloat16
+                and width in self.gram_widths):
             # Identity-shortcut blocks of layer1 / layer2 (64 / 128 channels into conv3, whose 256- / 512-channel output
             # is what the block's HBM traffic consists of): the batch statistics of conv3's output follow from the
             # 64 x 64 / 128 x 128 Gram matrix of its INPUT (one pass over a tensor a quarter of the output's size), so
