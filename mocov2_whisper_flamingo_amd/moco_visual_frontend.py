@@ -197,13 +197,19 @@ class MoCoVisualFrontend(nn.Module):
             ops.bn_gram_finalize(gp, cp, rows, e["wd"], bnd.weight.detach(), bnd.bias.detach(), bnd.running_mean,
                                  bnd.running_var, affd[0], affd[1], bnd.eps, bnd.momentum)
             idt = ops.conv_nhwc(y, e["wd"], 1, 1, 1, 0, scale=affd[0], bias=affd[1])
+            # conv1 reads the same input: bn1's statistics come from the same Gram matrix, bn1 + ReLU ride in conv1's epilogue
+            bn1 = blk.bn1
+            aff1 = torch.empty((2, e["w1"].shape[0]), dtype=torch.float32, device=y.device)
+            ops.bn_gram_finalize(gp, cp, rows, e["w1"], bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean,
+                                 bn1.running_var, aff1[0], aff1[1], bn1.eps, bn1.momentum)
+            h1 = ops.conv_nhwc(y, e["w1"], 1, 1, 1, 0, scale=aff1[0], bias=aff1[1], act=ops.ACT_RELU)
         elif "wd" in e:
             # batch statistics: the downsample BN has no activation, so its apply pass is folded into bn3's
             if self.training:
                 idt, idt_aff = self._conv_bn(y, e["wd"], 1, e["stride"], 0, blk.downsample[1], relu=False, defer=True)
             else:
                 idt = self._conv_bn(y, e["wd"], 1, e["stride"], 0, blk.downsample[1], relu=False)
-        h = self._conv_bn(y, e["w1"], 1, 1, 0, blk.bn1, relu=True)
+        h = h1 if gram_ds else self._conv_bn(y, e["w1"], 1, 1, 0, blk.bn1, relu=True)
         h = self._conv_bn(h, e["w2"], 3, e["stride"], 1, blk.bn2, relu=True)
         width = e["w3"].shape[1]
         if (self.training and self.gram_bn3 and ("wd" not in e or gram_ds) and h.dtype == torch.bfloat16
