@@ -445,6 +445,10 @@ def main():
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_launches": traffic_launches,
                     "algorithmic_bytes_per_launch": round(sum(r[2] for r in recs) / len(recs)),
+                    # the two per-launch figures average over different launch sets (the counters also see the small
+                    # products launched from C inside the fused blocks): compare the per-step totals
+                    "traffic_bytes_per_step": None if traffic is None else traffic * traffic_launches,
+                    "algorithmic_bytes_per_step": round(sum(r[2] for r in recs)),
                     "traffic_source": None if traffic is None else
                     f"profiles/{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, committed "
                     "with the code and read back here (not measured by this run)",
