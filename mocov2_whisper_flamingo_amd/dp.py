@@ -447,6 +447,7 @@ class GraphedTail:
         self.calls = 0
         self.rec = None
         self.failed = None
+        self.eager_steps = 0                 # steps after the recording whose shapes did not fit it
         import torch
         self._one = torch.ones((), dtype=torch.float32, device=trainer.device)
 
@@ -512,6 +513,12 @@ class GraphedTail:
         self.rec = {"g1": g1, "g2": g2, "st": st, "enc": s_enc, "record": record, "outs": outs, "step_cap": step0 + 1}
         tr.step_count = count0
 
+    def _fits(self, batch, encoded):
+        rec = self.rec
+        return (all(batch[k].shape == v.shape and batch[k].dtype == v.dtype for k, v in rec["st"].items()
+                    if k not in ("audio", "video"))
+                and encoded["enc"].shape == rec["enc"]["enc"].shape and encoded["vis"].shape == rec["enc"]["vis"].shape)
+
     @staticmethod
     def _fill(st, s_enc, batch, encoded):
         for k, dst in st.items():
@@ -540,6 +547,14 @@ class GraphedTail:
         rec = self.rec
         if encoded["inputs"][0] is not batch["audio"] or encoded["inputs"][2] is not batch["video"]:
             raise ValueError("`encoded` was computed for a different batch")
+        if not self._fits(batch, encoded):
+            # another shape than the recorded one (the short last batch of an epoch, a longer transcript): this step
+            # runs launch by launch, on the buffers the recording keeps reading
+            self.eager_steps += 1
+            out = self._eager(batch, encoded, lr)
+            self.model._cache.refresh_inplace()       # the weight copies stay where the recorded kernels read them
+            tr._scratch.zero_()                       # the recorded optimizer expects its sum of squares cleared
+            return out
         main = torch.cuda.current_stream()
         for stream, ev in encoded["done"]:
             main.wait_event(ev)

@@ -741,3 +741,37 @@ def test_gradient_overwrite_mode_follows_the_clearing_trajectory(dev, graphed, m
         if u0.numel() >= 1024:
             assert abs(u1.norm().item() / u0.norm().item() - 1.0) <= 2e-2, k
             assert torch.dot(u0, u1).item() >= 0.98 * u0.norm().item() * u1.norm().item(), k
+
+
+def test_graphed_tail_takes_an_odd_batch_launch_by_launch(dev):
+    """After the recording, a batch of another shape (fewer clips, a longer transcript) runs launch by launch on the
+    same weight copies and optimizer state, and the next batch of the recorded shape is replayed again: same losses
+    and updates as the all-eager run."""
+    import copy
+    from mocov2_whisper_flamingo_amd import dp
+    m0, _ = _micro_avnet(torch.bfloat16, dev, p_drop=0.0)
+    m0.train()
+    shapes = [dict(B=2, L=4), dict(B=2, L=4), dict(B=2, L=4), dict(B=1, L=4), dict(B=2, L=6), dict(B=2, L=4)]
+    batches = [to_device(synthetic_batch(Tv=6, H=32, W=32, vocab=503, seed=90 + i, **sh), dev) for i, sh in enumerate(shapes)]
+    runs = []
+    for graphed in (False, True):
+        m = copy.deepcopy(m0)
+        tr = dp.FlatTrainer(m, lr=1e-3, bucket_mb=0.25, overlap=False, grad_stream=False, fused_step=True)
+        tail = dp.GraphedTail(tr, warmup=2 if graphed else 10 ** 9)
+        losses = []
+        for b0 in batches:
+            b = dict(b0, video_lengths=b0["video_lengths"].clone())
+            losses.append(tail.step(b, m.encode(m.batch_inputs(b)))[0].detach().clone())
+        torch.cuda.synchronize()
+        assert tail.failed is None and (tail.rec is not None) == graphed
+        assert tail.eager_steps == (2 if graphed else 0)
+        runs.append((losses, {k: p.detach().clone() for k, p in m.named_parameters()}))
+    (l0, p0), (l1, p1) = runs
+    for a, b in zip(l0, l1):
+        assert abs(a.item() - b.item()) <= 2e-3 * abs(a.item())
+    start = dict(m0.named_parameters())
+    for k, _ in dp.trainable_parameters(m0):
+        u0, u1 = (p0[k] - start[k]).float().reshape(-1), (p1[k] - start[k]).float().reshape(-1)
+        if u0.numel() >= 4096:
+            assert abs(u1.norm().item() / u0.norm().item() - 1.0) <= 2e-2, k
+            assert torch.dot(u0, u1).item() >= 0.98 * u0.norm().item() * u1.norm().item(), k
