@@ -3,7 +3,7 @@ replaced by a no-op that returns a preallocated buffer (results are wrong on pur
 Standalone kernel times do not add up in this step - two encoder streams and the tail share the chip - so the marginal
 cost of a family is measured by removing it.
 usage: python scripts/ablate_step.py <family> [bench args]   family: none | attn | ln | bn_apply | maxpool | gemm_out |
-       gemm_fc2 | gemm_qkv | gemm_fc1 | conv3x3 | conv1x1 | stem | tail"""
+       gemm_fc2 | gemm_qkv | gemm_fc1 | conv3x3 | conv1x1 | stem | tail | bn_finalize"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -38,6 +38,10 @@ elif family == "bn_apply":
     def bn_apply(x, scale, shift, *, residual=None, residual_affine=None, relu=True, out=None, out_dtype=None):
         return out if out is not None else x
     ops.bn_apply = bn_apply
+elif family == "bn_finalize":
+    def bn_finalize(*a, **k):
+        return None
+    ops.bn_finalize = bn_finalize
 elif family == "maxpool":
     def maxpool(x, *, scale=None, shift=None, out_dtype=None):
         N, H, W, C = x.shape
