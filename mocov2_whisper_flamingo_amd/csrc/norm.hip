@@ -404,6 +404,9 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
     const int cc = min(c, C - 1);
     const int S = gridDim.y, slice = blockIdx.y;
     const int per = (nparts + S - 1) / S, p_end = min(nparts, (slice + 1) * per);
+    // the channel's parameters do not depend on the sums: request them now, not behind the reduction
+    float pw = 0.f, pb = 0.f, prm = 0.f, prv = 0.f;
+    if (w == 0) { pw = weight[cc]; pb = bias[cc]; if (running_mean) { prm = running_mean[cc]; prv = running_var[cc]; } }
     float a[8], b[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) { a[u] = 0.f; b[u] = 0.f; }
@@ -451,13 +454,13 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
     if (w != 0 || c >= C) return;
     const float mean = s / count;
     const float var = fmaxf(q / count - mean * mean, 0.f);
-    const float sc = weight[c] * rsqrtf(var + eps);
+    const float sc = pw * rsqrtf(var + eps);
     scale[c] = sc;
-    shift[c] = bias[c] - mean * sc;
+    shift[c] = pb - mean * sc;
     if (running_mean) {
         const float unb = count > 1.f ? var * count / (count - 1.f) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+        running_mean[c] = (1.f - momentum) * prm + momentum * mean;
+        running_var[c] = (1.f - momentum) * prv + momentum * unb;
     }
 }
 
