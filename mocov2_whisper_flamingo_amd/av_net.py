@@ -197,6 +197,7 @@ class AVNet(nn.Module):
                 if dst is not None:
                     dst.copy_(src)
             train_bn = self.visual_model.training
+            pending = self.visual_model._tracked_pending
             running = [b.clone() for b in self.visual_model.buffers()] if train_bn else []
             self.encode(st_in)
             stream.synchronize()
@@ -212,6 +213,7 @@ class AVNet(nn.Module):
                 with torch.cuda.graph(gv, stream=side, capture_error_mode="thread_local"):
                     vis = self._run_visual(st_in)
                 stream.wait_stream(side)
+                self.visual_model._tracked_pending = pending         # neither pass above was a training step
                 keep = (self.visual_model._packed, self.whisper_model.encoder._packed)
                 return ((ga, gv), st_in, enc, vis, keep)
             g = torch.cuda.CUDAGraph()
@@ -223,6 +225,7 @@ class AVNet(nn.Module):
                     cur.wait_event(ev)
         # the recorded kernels read the packed weight copies of this moment: the recording keeps them alive, so a later
         # re-pack (another module mode) cannot hand their memory to someone else
+        self.visual_model._tracked_pending = pending                 # neither pass above was a training step
         keep = (self.visual_model._packed, self.whisper_model.encoder._packed)
         return (g, st_in, out["enc"], out["vis"], keep)
 
@@ -256,6 +259,7 @@ class AVNet(nn.Module):
         g, st_in, enc_s, vis_s, _keep = rec
         if self.visual_model.training:
             self.visual_model._stats_epoch += 1                                  # the replay updates the running statistics
+            self.visual_model._tracked_pending += 1
         stream.wait_stream(main)                                                 # the inputs are ready on `main`
         with torch.cuda.stream(stream):
             for dst, src in zip(st_in, inputBatch):

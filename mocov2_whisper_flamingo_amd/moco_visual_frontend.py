@@ -80,7 +80,19 @@ class MoCoVisualFrontend(nn.Module):
         self.gram_downsample = os.environ.get("AVSR_GRAM_DS", "1") != "0"      # layer1.0's shortcut BN the same way
         self._packed = None
         self._stats_epoch = 0                   # bumped by every batch-statistics forward (the kernels write the buffers raw)
+        self._tracked_pending = 0               # training-mode forwards not yet added to num_batches_tracked
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_counters())
         self._blocks = list(self.MoCoModel.blocks())
+
+    def flush_counters(self):
+        """nn.BatchNorm's ``num_batches_tracked`` buffers count training-mode forwards and feed nothing here (momentum is
+        a number, not None): the count is kept on the host and added to the 54 buffers when someone looks - every
+        ``state_dict()`` does - instead of by a launch at the end of every forward."""
+        if self._tracked_pending:
+            with torch.no_grad():
+                torch._foreach_add_([m.num_batches_tracked for m in self.modules()
+                                     if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d))], self._tracked_pending)
+            self._tracked_pending = 0
 
     def stats_version(self):
         """Changes whenever the BN running statistics may have: a training-mode forward (here or replayed from a
@@ -242,8 +254,7 @@ class MoCoVisualFrontend(nn.Module):
         y = self.run_stem(video, pk)
         for i in range(len(self._blocks)):
             y = self.run_block(i, y, pk)
-        if self.training:   # one fused increment for all 54 counters
+        if self.training:
             self._stats_epoch += 1
-            torch._foreach_add_([m.num_batches_tracked for m in self.modules()
-                                 if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d))], 1)
+            self._tracked_pending += 1      # the 54 num_batches_tracked counters: see flush_counters
         return ops.avgpool_mask(y, x_len, B, T, self.compute_dtype)

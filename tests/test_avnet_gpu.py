@@ -320,6 +320,9 @@ def test_encoder_recordings_survive_a_mode_switch(dev):
             assert next(reversed(m._graphs)) == key and torch.equal(again["vis"], ref["vis"])
         seen[mode] = m._graphs[key][0]
     assert len(m._graphs) == 3
+    # two training-mode visits, each one eager pass and one replay: four counted forwards, kept on the host until
+    # a state_dict() asks for the buffers (the recording passes themselves count for nothing)
+    assert int(m.visual_model.state_dict()["MoCoModel.layer3.1.bn2.num_batches_tracked"]) == 4
     m.max_encoder_graphs = 1
     m.train(True)
     m.prune_unread_frames = False                                   # a third key
