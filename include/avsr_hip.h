@@ -356,7 +356,9 @@ int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq,
  * fp32 [parts, K], parts = avsr_gram_parts(M, K): per-share partial sums, plain stores, added in share order later.
  * avsr_bn_gram_finalize: W bf16 [N, K] (the convolution's weight as the product reads it), count = M; writes scale /
  * shift for the N output channels and updates the running statistics exactly as avsr_bn_finalize does.
- * workspace: avsr_bn_gram_workspace_doubles(K) doubles. */
+ * workspace: avsr_bn_gram_workspace_doubles(K) doubles; it is left holding the reduced statistics of the input, and a
+ * later call with gram_parts == colsum_parts == NULL and the same workspace (another convolution over the same
+ * input) uses them as they are instead of reducing the partials again. */
 int64_t avsr_gram_parts(int64_t M, int64_t K);
 int avsr_gram_stats(avsr_stream_t stream, const void* X, int64_t ldx, int64_t M, int64_t K, float* gram_parts,
                     float* colsum_parts);

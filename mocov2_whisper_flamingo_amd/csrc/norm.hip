@@ -651,13 +651,17 @@ extern "C" int avsr_bn_gram_finalize(avsr_stream_t stream, const float* gram_par
                                      int64_t K, double count, const void* W_bf16, int64_t ldw, int64_t N, const float* weight,
                                      const float* bias, float* running_mean, float* running_var, float* scale, float* shift,
                                      float eps, float momentum, double* workspace) {
-    if (!gram_parts || !colsum_parts || !W_bf16 || !weight || !bias || !scale || !shift || !workspace) return AVSR_EINVAL;
-    if (parts <= 0 || N <= 0 || count <= 0 || ldw < K) return AVSR_EINVAL;
+    // gram_parts == NULL (with colsum_parts == NULL): the workspace already holds the reduced statistics of this input
+    // from an earlier call (several convolutions reading one tensor: one reduction serves them all)
+    if ((gram_parts == nullptr) != (colsum_parts == nullptr)) return AVSR_EINVAL;
+    if (!W_bf16 || !weight || !bias || !scale || !shift || !workspace) return AVSR_EINVAL;
+    if ((gram_parts && parts <= 0) || N <= 0 || count <= 0 || ldw < K) return AVSR_EINVAL;
     if (K != 64 && K != 128) return AVSR_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const int KK = (int)(K * K);
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((KK + K + 63) / 64)), dim3(1024), 0, s, gram_parts, colsum_parts,
-                       (int)parts, KK, (int)K, 1.0 / count, (float*)workspace);
+    if (gram_parts)
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((KK + K + 63) / 64)), dim3(1024), 0, s, gram_parts, colsum_parts,
+                           (int)parts, KK, (int)K, 1.0 / count, (float*)workspace);
     const size_t lds = (size_t)(KK + K + 4 * K) * sizeof(float);
     const dim3 grid((unsigned)((N + GRAM_FIN_CH - 1) / GRAM_FIN_CH));
     const float* gm = (const float*)workspace;

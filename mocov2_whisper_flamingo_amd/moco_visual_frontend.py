@@ -206,14 +206,14 @@ class MoCoVisualFrontend(nn.Module):
             rows = y.numel() // Cin
             gp, cp = ops.gram_stats(y.view(rows, Cin))
             affd = torch.empty((2, C), dtype=torch.float32, device=y.device)
-            ops.bn_gram_finalize(gp, cp, rows, e["wd"], bnd.weight.detach(), bnd.bias.detach(), bnd.running_mean,
-                                 bnd.running_var, affd[0], affd[1], bnd.eps, bnd.momentum)
+            red = ops.bn_gram_finalize(gp, cp, rows, e["wd"], bnd.weight.detach(), bnd.bias.detach(), bnd.running_mean,
+                                       bnd.running_var, affd[0], affd[1], bnd.eps, bnd.momentum)
             idt = ops.conv_nhwc(y, e["wd"], 1, 1, 1, 0, scale=affd[0], bias=affd[1])
             # conv1 reads the same input: bn1's statistics come from the same Gram matrix, bn1 + ReLU ride in conv1's epilogue
             bn1 = blk.bn1
             aff1 = torch.empty((2, e["w1"].shape[0]), dtype=torch.float32, device=y.device)
             ops.bn_gram_finalize(gp, cp, rows, e["w1"], bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean,
-                                 bn1.running_var, aff1[0], aff1[1], bn1.eps, bn1.momentum)
+                                 bn1.running_var, aff1[0], aff1[1], bn1.eps, bn1.momentum, reduced=red)
             h1 = ops.conv_nhwc(y, e["w1"], 1, 1, 1, 0, scale=aff1[0], bias=aff1[1], act=ops.ACT_RELU)
         elif "wd" in e:
             # batch statistics: the downsample BN has no activation, so its apply pass is folded into bn3's

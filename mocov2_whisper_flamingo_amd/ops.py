@@ -480,19 +480,23 @@ def gram_stats(x):
 
 
 def bn_gram_finalize(gram_parts, colsum_parts, count, w, weight, bias, running_mean, running_var, scale, shift,
-                     eps=1e-5, momentum=0.1):
+                     eps=1e-5, momentum=0.1, reduced=None):
     """Training-mode BN affine (and running-statistics update) of the 1x1 convolution with weight ``w`` (bf16 [N, K])
-    from the input's Gram statistics (gram_stats)."""
+    from the input's Gram statistics (gram_stats).  Returns the workspace holding the reduced statistics; pass it back
+    as ``reduced`` for another convolution over the SAME input (the partials are then not reduced again)."""
     lib = _lib.load()
     parts, K = colsum_parts.shape
     N = w.shape[0]
     if w.dtype != torch.bfloat16 or w.stride(1) != 1 or w.shape[1] != K:
         raise ValueError("bn_gram_finalize: w must be bf16 [N, K]")
-    ws = torch.empty(int(lib.avsr_bn_gram_workspace_doubles(K)), dtype=torch.float64, device=w.device)
-    check(lib.avsr_bn_gram_finalize(_stream(), gram_parts.data_ptr(), colsum_parts.data_ptr(), parts, K, float(count),
+    ws = reduced if reduced is not None else torch.empty(int(lib.avsr_bn_gram_workspace_doubles(K)), dtype=torch.float64,
+                                                          device=w.device)
+    check(lib.avsr_bn_gram_finalize(_stream(), None if reduced is not None else gram_parts.data_ptr(),
+                                    None if reduced is not None else colsum_parts.data_ptr(), parts, K, float(count),
                                     w.data_ptr(), w.stride(0), N, weight.data_ptr(), bias.data_ptr(), _p(running_mean),
                                     _p(running_var), scale.data_ptr(), shift.data_ptr(), eps, momentum, ws.data_ptr()),
           "avsr_bn_gram_finalize")
+    return ws
 
 
 _BN_TICKETS = {}     # (device, stream) -> int32 ticket counters of the split batch-norm reduction
