@@ -318,6 +318,12 @@ int64_t avsr_stem3d_frag_elems(void);
 int avsr_stem3d_pack_frags(avsr_stream_t stream, const float* weight_packed, void* weight_frags);
 int avsr_maxpool3x3s2(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y,
                       const float* scale, const float* shift, int64_t N, int64_t H, int64_t W, int64_t C);
+/* The two steps before it in training mode as one launch: the last Bottleneck's bn3 apply + shortcut + ReLU (torchvision
+ * Bottleneck.forward, instantiated at moco_visual_frontend.py:27-31) and the pool + mask (:41-51) - the normalised
+ * activation nobody else reads is never written.  x, residual: bf16 [B*T, HW, C]; y [B*T, C] bf16 or fp32. */
+int avsr_bn_apply_avgpool_mask(avsr_stream_t stream, int out_dtype, const void* x, const void* residual,
+                               const float* scale, const float* shift, void* y, const int64_t* lens, int64_t B,
+                               int64_t T, int64_t HW, int64_t C);
 int avsr_avgpool_mask_fwd(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y,
                           const int64_t* lens, int64_t B, int64_t T, int64_t HW, int64_t C);
 /* VideoTransform of the data path (datamodule/transforms.py:61-96) for frames already in device memory:

@@ -717,6 +717,66 @@ extern "C" int avsr_video_color(avsr_stream_t stream, float* video, int64_t B, i
     return avsr_launch_status();
 }
 
+// The trunk's last BN apply (affine + shortcut + ReLU) folded into the average pool: the normalised 2048-channel
+// activation is consumed by nothing else, so it is never written.  y[frame, c] = mean over the HW pixels of
+// relu(x * scale[c] + shift[c] + residual), zero for frames t >= lens[b].  A thread owns 8 channels of a frame.
+template <typename TO>
+__global__ __launch_bounds__(256) void bn_apply_avgpool_bf16x8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                      TO* __restrict__ y, const int64_t* __restrict__ lens, int Tn,
+                                                                      int HW, int C8) {
+    const int frame = blockIdx.x;
+    const int cg = blockIdx.y * blockDim.x + threadIdx.x;
+    if (cg >= C8) return;
+    const int b = frame / Tn, t = frame - b * Tn;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (!(lens && t >= lens[b])) {
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = scale[cg * 8 + e]; sh[e] = shift[cg * 8 + e]; }
+        const long base = ((long)frame * HW * C8 + cg) * 8, step = (long)C8 * 8;
+        for (int p0 = 0; p0 < HW; p0 += 8) {
+            bf16x8 v[8], r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long o = base + (long)min(p0 + u, HW - 1) * step;
+                v[u] = *(const bf16x8*)(x + o);
+                r[u] = *(const bf16x8*)(res + o);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (p0 + u < HW) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[e] += fmaxf(fmaf((float)v[u][e], sc[e], sh[e]) + (float)r[u][e], 0.f);
+                }
+        }
+    }
+    const float inv = 1.0f / (float)HW;
+    TO* yp = y + ((long)frame * C8 + cg) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) yp[e] = from_f32<TO>(s[e] * inv);
+}
+
+extern "C" int avsr_bn_apply_avgpool_mask(avsr_stream_t stream, int out_dtype, const void* x, const void* residual,
+                                          const float* scale, const float* shift, void* y, const int64_t* lens, int64_t B,
+                                          int64_t T, int64_t HW, int64_t C) {
+    if (!x || !residual || !scale || !shift || !y || B <= 0 || T <= 0 || HW <= 0 || C <= 0) return AVSR_EINVAL;
+    if (C % 8 || ((uintptr_t)x | (uintptr_t)residual) % 16 || B * T > 0x7fffffff) return AVSR_EUNSUPPORTED;
+    const int C8 = (int)(C / 8);
+    dim3 grid((unsigned)(B * T), (unsigned)((C8 + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == AVSR_BF16)
+        hipLaunchKernelGGL(bn_apply_avgpool_bf16x8_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, (const bf16_t*)residual,
+                           scale, shift, (bf16_t*)y, lens, (int)T, (int)HW, C8);
+    else if (out_dtype == AVSR_F32)
+        hipLaunchKernelGGL(bn_apply_avgpool_bf16x8_kernel<float>, grid, block, 0, s, (const bf16_t*)x, (const bf16_t*)residual,
+                           scale, shift, (float*)y, lens, (int)T, (int)HW, C8);
+    else return AVSR_EINVAL;
+    return avsr_launch_status();
+}
+
 extern "C" int avsr_avgpool_mask_fwd(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, void* y,
                                      const int64_t* lens, int64_t B, int64_t T, int64_t HW, int64_t C) {
     if (!x || !y || B <= 0 || T <= 0 || HW <= 0 || C <= 0) return AVSR_EINVAL;

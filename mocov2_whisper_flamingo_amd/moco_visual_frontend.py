@@ -187,8 +187,10 @@ class MoCoVisualFrontend(nn.Module):
         return ops.maxpool3x3s2(raw, scale=aff[0], shift=aff[1])
 
     @torch.no_grad()
-    def run_block(self, index, y, pk=None):
-        """One Bottleneck (index 0..15 over layer1..layer4) on an NHWC tensor."""
+    def run_block(self, index, y, pk=None, pool=None):
+        """One Bottleneck (index 0..15 over layer1..layer4) on an NHWC tensor.  ``pool`` = (x_len, B, T), last block
+        only: return the pooled, masked [B, T, C] features where the block can fold the pool into its last pass
+        (the caller checks the rank of what comes back)."""
         pk = pk or self._pack(self.compute_dtype)
         e = pk["blocks"][index]
         blk = self._blocks[index]
@@ -240,6 +242,15 @@ class MoCoVisualFrontend(nn.Module):
                                  bn3.running_var, aff[0], aff[1], bn3.eps, bn3.momentum)
             return ops.conv_nhwc(h, e["w3"], 1, 1, 1, 0, scale=aff[0], bias=aff[1], act=ops.ACT_RELU_AFTER_RESIDUAL,
                                  residual=idt.view(-1, C))
+        if pool is not None and self.training and idt_aff is None and h.dtype == torch.bfloat16:
+            # the trunk's last block: nothing but the average pool reads its output, so bn3's apply pass, the
+            # shortcut and the ReLU ride in the pool and the normalised 2048-channel tensor is never written
+            raw, aff3 = self._conv_bn(h, e["w3"], 1, 1, 0, blk.bn3, relu=False, defer=True)
+            x_len, B, T = pool
+            if aff3 is not None:
+                return ops.bn_apply_avgpool_mask(raw, idt.view(raw.shape), aff3[0], aff3[1], x_len, B, T, self.compute_dtype)
+            return ops.bn_apply(raw, torch.ones_like(blk.bn3.weight), torch.zeros_like(blk.bn3.weight), residual=idt,
+                                relu=True, out=raw)                      # (two-pass option: already normalised)
         return self._conv_bn(h, e["w3"], 1, 1, 0, blk.bn3, relu=True, residual=idt, residual_affine=idt_aff)
 
     @torch.no_grad()
@@ -252,9 +263,10 @@ class MoCoVisualFrontend(nn.Module):
         video = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
         pk = self._pack(self.compute_dtype)        # one weight-version check per forward
         y = self.run_stem(video, pk)
-        for i in range(len(self._blocks)):
-            y = self.run_block(i, y, pk)
+        last = len(self._blocks) - 1
+        for i in range(last + 1):
+            y = self.run_block(i, y, pk, pool=(x_len, B, T) if i == last else None)
         if self.training:
             self._stats_epoch += 1
             self._tracked_pending += 1      # the 54 num_batches_tracked counters: see flush_counters
-        return ops.avgpool_mask(y, x_len, B, T, self.compute_dtype)
+        return y if y.dim() == 3 else ops.avgpool_mask(y, x_len, B, T, self.compute_dtype)

@@ -444,6 +444,23 @@ def avgpool_mask(x, lens, B, T, out_dtype):
     return y
 
 
+def bn_apply_avgpool_mask(x, residual, scale, shift, lens, B, T, out_dtype):
+    """mean over pixels of relu(x * scale + shift + residual) for NHWC bf16 x / residual [B*T,h,w,C] -> [B,T,C], frames
+    t >= lens[b] zeroed: the trunk's last BN apply and the average pool in one pass."""
+    lib = _lib.load()
+    _need_cuda(x, residual, scale, shift)
+    n, h, w, C = x.shape
+    if x.dtype != torch.bfloat16 or residual.dtype != torch.bfloat16 or residual.shape != x.shape:
+        raise ValueError("bn_apply_avgpool_mask takes bf16 NHWC tensors of one shape")
+    if not (x.is_contiguous() and residual.is_contiguous()):
+        raise ValueError("bn_apply_avgpool_mask takes contiguous tensors")
+    y = torch.empty((B, T, C), dtype=out_dtype, device=x.device)
+    check(lib.avsr_bn_apply_avgpool_mask(_stream(), _DT[out_dtype], x.data_ptr(), residual.data_ptr(), scale.data_ptr(),
+                                         shift.data_ptr(), y.data_ptr(), _p(lens), B, T, h * w, C),
+          "avsr_bn_apply_avgpool_mask")
+    return y
+
+
 def bn_finalize(col_sum, col_sumsq, count, weight, bias, running_mean, running_var, scale, shift, eps=1e-5, momentum=0.1):
     """col_sum / col_sumsq: [parts, C] partial-sum slabs (or [C])."""
     lib = _lib.load()

@@ -570,6 +570,23 @@ def test_bn_finalize_slabs(dev, nparts, C):
     assert all(int(t.abs().sum()) == 0 for t in ops._BN_TICKETS.values())
 
 
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("hw,C", [((4, 4), 2048), ((3, 3), 64), ((1, 5), 4096)])
+def test_bn_apply_folded_into_the_average_pool(dev, odt, hw, C):
+    g = torch.Generator().manual_seed(C)
+    B, T = 2, 5
+    x = rnd(g, B * T, hw[0], hw[1], C, dtype=torch.bfloat16)
+    r = rnd(g, B * T, hw[0], hw[1], C, dtype=torch.bfloat16)
+    sc, sh = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.3
+    lens = torch.tensor([5, 3])
+    ref = F.relu(x * sc + sh + r).mean((1, 2)).view(B, T, C)
+    ref[1, 3:] = 0
+    got = ops.bn_apply_avgpool_mask(x.to(dev, torch.bfloat16), r.to(dev, torch.bfloat16), sc.to(dev), sh.to(dev),
+                                    lens.to(dev), B, T, odt)
+    assert got.dtype == odt and rel_err(got, ref) < tol(odt if odt == torch.bfloat16 else torch.float32) * (1 if odt == torch.bfloat16 else 5)
+    assert (got[1, 3:] == 0).all()
+
+
 @pytest.mark.parametrize("shape", [(3, 50, 50, 64), (2, 13, 17, 128), (1, 7, 9, 256), (2, 5, 70, 64), (2, 24, 24, 8)])
 def test_maxpool_bf16_bands(dev, shape):
     """The 16-byte bf16 max-pool (bands of output rows, the shared input row carried in registers): odd sizes,
