@@ -312,6 +312,16 @@ int avsr_logmel_augment_fwd(avsr_stream_t stream, int out_dtype, const float* wa
 int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float* video, const float* weight_packed,
                     const void* weight_frags, void* out, const float* scale, const float* shift, float* col_sum,
                     float* col_sumsq, int64_t B, int64_t T, int64_t H, int64_t W);
+/* avsr_stem3d_fwd whose input address is read from the 8-byte device word *video_slot when the kernel RUNS (no
+ * counterpart in the reference: a launch recorded in a HIP graph then follows the caller's current batch -
+ * models/av_net.py:240 hands a fresh videoBatch every step - without a copy into a fixed buffer).  bf16 MFMA form
+ * only (weight_frags required, W % 4 == 0); the stored address must be 16-byte aligned and stay valid until the
+ * launch has finished.  avsr_store_u64 writes such a word in stream order. */
+int avsr_stem3d_fwd_indirect(avsr_stream_t stream, int out_dtype, const float* const* video_slot,
+                             const float* weight_packed, const void* weight_frags, void* out, const float* scale,
+                             const float* shift, float* col_sum, float* col_sumsq, int64_t B, int64_t T, int64_t H,
+                             int64_t W);
+int avsr_store_u64(avsr_stream_t stream, uint64_t* dst, uint64_t value);
 int64_t avsr_stem3d_stats_parts(int64_t B, int64_t T, int64_t H, int64_t W);
 /* bf16 MFMA-fragment copy of the stem weight (avsr_stem3d_frag_elems() bf16 values) from weight_packed */
 int64_t avsr_stem3d_frag_elems(void);

@@ -91,6 +91,8 @@ class AVNet(nn.Module):
         # one recording per encoder, replayed on two streams (AVSR_SPLIT_ENC_GRAPHS=0: both encoders in one recording,
         # whose two branches the runtime largely takes in turn: 7.33 ms per benchmark step against 7.26)
         self.split_encoder_graphs = os.environ.get("AVSR_SPLIT_ENC_GRAPHS", "1") != "0"
+        self.video_in_place = os.environ.get("AVSR_VIDEO_IN_PLACE", "1") != "0"
+        self._capture_slot = None
         self._seed_delta = None             # device record of a graphed training step (dp.GraphedTail), else None
         self.fusion_module.set_runtime(self._cache, self._dropout_seed, lambda: self._seed_delta)
         if device is not None:
@@ -165,7 +167,14 @@ class AVNet(nn.Module):
         return {"enc": enc, "vis": vis, "done": done, "inputs": inputBatch}
 
     def _run_visual(self, inputBatch):
-        return self.visual_model(inputBatch[2], inputBatch[4])
+        return self.visual_model(inputBatch[2], inputBatch[4], video_slot=self._capture_slot)
+
+    @staticmethod
+    def _video_in_place(videoBatch):
+        """The batch as the stem can read it where it lies: fp32, contiguous, 16-byte aligned (else such a copy)."""
+        if videoBatch.dtype == torch.float32 and videoBatch.is_contiguous():
+            return videoBatch if videoBatch.data_ptr() % 16 == 0 else videoBatch.clone()
+        return videoBatch.float().contiguous()
 
     def _run_audio(self, inputBatch):
         audioBatch, videoBatch = inputBatch[0], inputBatch[2]
@@ -190,44 +199,59 @@ class AVNet(nn.Module):
     def _capture_encoders(self, inputBatch, stream, main):
         """Static input buffers, one eager pass (weight packing, lazily set kernel attributes), then the capture."""
         audioBatch, _, videoBatch, _, videoLen = inputBatch
-        st_in = (torch.empty_like(audioBatch), None, torch.empty_like(videoBatch), None, torch.empty_like(videoLen))
+        # The video (by far the largest input) is not copied into a buffer of the recording: the stem reads its address
+        # from a device word that every replay sets to the caller's current batch.
+        slot = torch.zeros(1, dtype=torch.int64, device=audioBatch.device) if self.video_in_place else None
         stream.wait_stream(main)
         with torch.cuda.stream(stream):
-            for dst, src in zip(st_in, inputBatch):
-                if dst is not None:
-                    dst.copy_(src)
             train_bn = self.visual_model.training
             pending = self.visual_model._tracked_pending
             running = [b.clone() for b in self.visual_model.buffers()] if train_bn else []
-            self.encode(st_in)
-            stream.synchronize()
-            for b, saved in zip(self.visual_model.buffers(), running):      # the warm-up must not count as a step
-                b.copy_(saved)
-            if self.split_encoder_graphs:
-                # one recording per encoder, replayed on two streams: two launch queues instead of one
-                ga, gv = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, stream=stream, capture_error_mode="thread_local"):
-                    enc = self._run_audio(st_in)
-                side = self._side_stream
-                side.wait_stream(stream)
-                with torch.cuda.graph(gv, stream=side, capture_error_mode="thread_local"):
-                    vis = self._run_visual(st_in)
-                stream.wait_stream(side)
+            try:
+                while True:
+                    video = self._video_in_place(videoBatch) if slot is not None else videoBatch.clone()
+                    st_in = (audioBatch.clone(), None, video, None, videoLen.clone())
+                    self._capture_slot = slot
+                    try:
+                        if slot is not None:
+                            ops.store_u64(slot, video.data_ptr())
+                        self.encode(st_in)
+                        break
+                    except ops._lib.AvsrHipError:
+                        if slot is None:
+                            raise
+                        slot = None                 # a stem form that cannot take the indirection: fixed input buffer
+                stream.synchronize()
+                for b, saved in zip(self.visual_model.buffers(), running):  # the warm-up must not count as a step
+                    b.copy_(saved)
+                if self.split_encoder_graphs:
+                    # one recording per encoder, replayed on two streams: two launch queues instead of one
+                    g = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
+                    with torch.cuda.graph(g[0], stream=stream, capture_error_mode="thread_local"):
+                        enc = self._run_audio(st_in)
+                    side = self._side_stream
+                    side.wait_stream(stream)
+                    with torch.cuda.graph(g[1], stream=side, capture_error_mode="thread_local"):
+                        vis = self._run_visual(st_in)
+                    stream.wait_stream(side)
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    # thread_local: a communicator's watchdog thread may touch the runtime while this thread records
+                    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                        out = self.encode(st_in)
+                        cur = torch.cuda.current_stream()
+                        for _side, ev in out["done"]:                        # join the visual stream into the capture
+                            cur.wait_event(ev)
+                    enc, vis = out["enc"], out["vis"]
+            finally:
+                self._capture_slot = None
                 self.visual_model._tracked_pending = pending         # neither pass above was a training step
-                keep = (self.visual_model._packed, self.whisper_model.encoder._packed)
-                return ((ga, gv), st_in, enc, vis, keep)
-            g = torch.cuda.CUDAGraph()
-            # thread_local: a communicator's watchdog thread may touch the runtime while this thread records
-            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                out = self.encode(st_in)
-                cur = torch.cuda.current_stream()
-                for side, ev in out["done"]:                                 # join the visual stream into the capture
-                    cur.wait_event(ev)
         # the recorded kernels read the packed weight copies of this moment: the recording keeps them alive, so a later
         # re-pack (another module mode) cannot hand their memory to someone else
-        self.visual_model._tracked_pending = pending                 # neither pass above was a training step
         keep = (self.visual_model._packed, self.whisper_model.encoder._packed)
-        return (g, st_in, out["enc"], out["vis"], keep)
+        if slot is not None:
+            st_in = (st_in[0], None, None, None, st_in[4])           # the first batch's video is not the recording's to hold
+        return (g, st_in, enc, vis, keep, slot)
 
     def _encode_graph(self, inputBatch, ahead):
         audioBatch, _, videoBatch, _, videoLen = inputBatch
@@ -256,32 +280,43 @@ class AVNet(nn.Module):
             self._graphs[key] = self._graphs.pop(key)                            # most recently used last
         if rec is False:
             return self.encode(inputBatch, ahead=ahead)
-        g, st_in, enc_s, vis_s, _keep = rec
+        g, st_in, enc_s, vis_s, _keep, slot = rec
+        split = isinstance(g, tuple)
+        # the stream the visual recording runs on: its inputs (video or its address, the lengths) are written in THAT
+        # stream's order, behind the previous replay that still reads them
+        vstream = self._side_stream if split else stream
+        video = self._video_in_place(videoBatch) if slot is not None else None
         if self.visual_model.training:
             self.visual_model._stats_epoch += 1                                  # the replay updates the running statistics
             self.visual_model._tracked_pending += 1
         stream.wait_stream(main)                                                 # the inputs are ready on `main`
-        with torch.cuda.stream(stream):
-            for dst, src in zip(st_in, inputBatch):
-                if dst is not None:
-                    dst.copy_(src, non_blocking=True)
-            if isinstance(g, tuple):
-                ready = stream.record_event()
-                g[0].replay()
-                enc = enc_s.clone()
-                ev = stream.record_event()
+        if split:
+            vstream.wait_stream(main)
+
+        def visual_inputs():
+            st_in[4].copy_(videoLen, non_blocking=True)
+            if slot is None:
+                st_in[2].copy_(videoBatch, non_blocking=True)
             else:
+                ops.store_u64(slot, video.data_ptr())
+                video.record_stream(vstream)
+
+        with torch.cuda.stream(stream):
+            st_in[0].copy_(audioBatch, non_blocking=True)
+            if split:
+                g[0].replay()
+                enc = enc_s.clone()                           # the next replay overwrites the recording's outputs
+            else:
+                visual_inputs()
                 g.replay()
-                enc, vis = enc_s.clone(), vis_s.clone()       # the next replay overwrites the recording's outputs
-                ev = stream.record_event()
-        done = [(stream, ev)]
-        if isinstance(g, tuple):
-            side = self._side_stream
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
+                enc, vis = enc_s.clone(), vis_s.clone()
+            done = [(stream, stream.record_event())]
+        if split:
+            with torch.cuda.stream(vstream):
+                visual_inputs()
                 g[1].replay()
                 vis = vis_s.clone()
-                done.append((side, side.record_event()))
+                done.append((vstream, vstream.record_event()))
         if not ahead:
             for _, e in done:
                 main.wait_event(e)

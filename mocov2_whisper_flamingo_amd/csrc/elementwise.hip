@@ -512,6 +512,17 @@ struct StepRecord { unsigned long long seed_delta; float lr, bc1, bc2; unsigned 
 static_assert(sizeof(StepRecord) == 32, "the step record is 32 bytes");
 __global__ void step_params_kernel(StepRecord* rec, StepRecord v) { *rec = v; }
 
+__global__ void store_u64_kernel(unsigned long long* dst, unsigned long long v) { *dst = v; }
+
+// One 8-byte word written in stream order (the value travels in the launch packet): e.g. the address a recorded
+// launch reads its input from (avsr_stem3d_fwd_indirect).
+extern "C" int avsr_store_u64(avsr_stream_t stream, uint64_t* dst, uint64_t value) {
+    if (!dst || (uintptr_t)dst % 8) return AVSR_EINVAL;
+    hipLaunchKernelGGL(store_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)dst,
+                       (unsigned long long)value);
+    return avsr_launch_status();
+}
+
 extern "C" int avsr_step_params(avsr_stream_t stream, void* record, uint64_t seed_delta, float lr, float beta1, float beta2,
                                 int64_t step) {
     if (!record || step <= 0 || ((uintptr_t)record % 8) != 0) return AVSR_EINVAL;

@@ -142,11 +142,14 @@ __global__ void stem3d_pack_frags_kernel(const float* __restrict__ wpacked, bf16
 // phase of the other).  Statistics of item i go to slab row clip*parts_per_clip + i; the rows of a clip no
 // item owns are zeroed by the clip's first item.
 #define SM_F 4
-__global__ __launch_bounds__(256, 2) void stem3d_mfma_kernel(const float* __restrict__ video, const bf16_t* __restrict__ frags,
+__global__ __launch_bounds__(256, 2) void stem3d_mfma_kernel(const float* __restrict__ video_arg, const bf16_t* __restrict__ frags,
                                                          bf16_t* __restrict__ out, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float* __restrict__ csum,
                                                          float* __restrict__ csq, int B, int T, int H, int W, int OH, int OW,
-                                                         int rows, int parts_per_clip) {
+                                                         int rows, int parts_per_clip, const float* const* video_slot) {
+    // video_slot: the input's address is read from device memory when the kernel runs (a launch recorded in a HIP
+    // graph then follows the caller's current batch without a copy of the batch into a fixed buffer)
+    const float* __restrict__ video = video_slot ? *video_slot : video_arg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* win = (bf16_t*)smem;                     // [(SM_F+4)*3 planes][2*rows+1][PW]
     const int PW = W + 8, WR = 2 * rows + 1, NPL = (SM_F + 4) * 3;
@@ -622,9 +625,31 @@ extern "C" int avsr_stem3d_pack_frags(avsr_stream_t stream, const float* weight_
     return avsr_launch_status();
 }
 
+static int stem3d_fwd_impl(avsr_stream_t stream, int out_dtype, const float* video, const float* const* video_slot,
+                           const float* weight_packed, const void* weight_frags, void* out, const float* scale,
+                           const float* shift, float* col_sum, float* col_sumsq, int64_t B, int64_t T, int64_t H, int64_t W);
+
 extern "C" int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float* video, const float* weight_packed,
                                const void* weight_frags, void* out, const float* scale, const float* shift,
                                float* col_sum, float* col_sumsq, int64_t B, int64_t T, int64_t H, int64_t W) {
+    return stem3d_fwd_impl(stream, out_dtype, video, nullptr, weight_packed, weight_frags, out, scale, shift, col_sum,
+                           col_sumsq, B, T, H, W);
+}
+
+extern "C" int avsr_stem3d_fwd_indirect(avsr_stream_t stream, int out_dtype, const float* const* video_slot,
+                                        const float* weight_packed, const void* weight_frags, void* out,
+                                        const float* scale, const float* shift, float* col_sum, float* col_sumsq,
+                                        int64_t B, int64_t T, int64_t H, int64_t W) {
+    if (!video_slot || (uintptr_t)video_slot % 8) return AVSR_EINVAL;
+    // the host cannot see the address the kernel will read: a 16-byte-aligned stand-in passes the checks below
+    return stem3d_fwd_impl(stream, out_dtype, (const float*)(uintptr_t)16, video_slot, weight_packed, weight_frags, out, scale,
+                           shift, col_sum, col_sumsq, B, T, H, W);
+}
+
+
+static int stem3d_fwd_impl(avsr_stream_t stream, int out_dtype, const float* video, const float* const* video_slot,
+                           const float* weight_packed, const void* weight_frags, void* out, const float* scale,
+                           const float* shift, float* col_sum, float* col_sumsq, int64_t B, int64_t T, int64_t H, int64_t W) {
     if (!video || !weight_packed || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0) return AVSR_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return AVSR_EINVAL;
     if ((col_sum == nullptr) != (col_sumsq == nullptr)) return AVSR_EINVAL;
@@ -642,9 +667,11 @@ extern "C" int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float*
         const long nitems = B * ((T + SM_F - 1) / SM_F) * ((OH + rows - 1) / rows);
         const unsigned nblk = (unsigned)(nitems < 512 ? nitems : 512);      // persistent: two workgroups per CU
         hipLaunchKernelGGL(stem3d_mfma_kernel, dim3(nblk), dim3(256), lds, s, video, (const bf16_t*)weight_frags,
-                           (bf16_t*)out, scale, shift, col_sum, col_sumsq, (int)B, (int)T, (int)H, (int)W, OH, OW, rows, ppc);
+                           (bf16_t*)out, scale, shift, col_sum, col_sumsq, (int)B, (int)T, (int)H, (int)W, OH, OW, rows, ppc,
+                           video_slot);
         return avsr_launch_status();
     }
+    if (video_slot) return AVSR_EUNSUPPORTED;               // only the MFMA form reads its input through the slot
     dim3 grid((unsigned)((OH * OW + 64 * ST_ROUNDS - 1) / (64 * ST_ROUNDS)), (unsigned)(B * T));
     if (out_dtype == AVSR_F32)
         hipLaunchKernelGGL(stem3d_kernel<float>, grid, dim3(256), 0, s, video, weight_packed, (float*)out, scale, shift,

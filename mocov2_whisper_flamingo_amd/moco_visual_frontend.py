@@ -171,16 +171,19 @@ class MoCoVisualFrontend(nn.Module):
         return ops.bn_apply(raw, aff[0], aff[1], residual=residual, residual_affine=residual_affine, relu=relu, out=raw)
 
     @torch.no_grad()
-    def run_stem(self, video, pk=None):
-        """frontend3D on fp32 video [B,T,3,H,W] -> NHWC [B*T, H/4, W/4, 64] in the compute dtype."""
+    def run_stem(self, video, pk=None, video_slot=None):
+        """frontend3D on fp32 video [B,T,3,H,W] -> NHWC [B*T, H/4, W/4, 64] in the compute dtype.
+        ``video_slot``: see ops.stem3d_fwd (the input's address is read from that device word when the kernel runs)."""
         dtype = self.compute_dtype
         pk = pk or self._pack(dtype)
         bn0 = self.frontend3D[1]
         if not self.training:
             sc, sh = self._fold(bn0)
-            return ops.maxpool3x3s2(ops.stem3d_fwd(video, pk["stem_w"], dtype, scale=sc, shift=sh, frags=pk["stem_f"]))
+            return ops.maxpool3x3s2(ops.stem3d_fwd(video, pk["stem_w"], dtype, scale=sc, shift=sh, frags=pk["stem_f"],
+                                                   video_slot=video_slot))
         stats = ops.stem_stats_slabs(video)
-        raw = ops.stem3d_fwd(video, pk["stem_w"], dtype, col_stats=(stats[0], stats[1]), frags=pk["stem_f"])
+        raw = ops.stem3d_fwd(video, pk["stem_w"], dtype, col_stats=(stats[0], stats[1]), frags=pk["stem_f"],
+                             video_slot=video_slot)
         aff = torch.empty((2, 64), dtype=torch.float32, device=video.device)
         ops.bn_finalize(stats[0], stats[1], raw.numel() // 64, bn0.weight.detach(), bn0.bias.detach(),
                         bn0.running_mean, bn0.running_var, aff[0], aff[1], bn0.eps, bn0.momentum)
@@ -254,15 +257,19 @@ class MoCoVisualFrontend(nn.Module):
         return self._conv_bn(h, e["w3"], 1, 1, 0, blk.bn3, relu=True, residual=idt, residual_affine=idt_aff)
 
     @torch.no_grad()
-    def forward(self, x, x_len):
+    def forward(self, x, x_len, video_slot=None):
         """x: [B,T,3,H,W] (or [B,1,T,3,H,W]) fp32, x_len: int64 [B] -> [B,T,2048]
-        in the compute dtype, rows t >= x_len[b] zero."""
+        in the compute dtype, rows t >= x_len[b] zero.
+        ``video_slot`` (one-element int64 GPU tensor): the stem reads the video's address from it when it runs and
+        ``x`` only gives the shape - for a caller that records this forward once and replays it on other batches."""
         if x.dim() == 6 and x.shape[1] == 1:
             x = x.squeeze(1)
         B, T = x.shape[0], x.shape[1]
         video = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+        if video_slot is not None and video is not x:
+            raise ValueError("video_slot needs contiguous fp32 video (a converted copy would be read at a fixed address)")
         pk = self._pack(self.compute_dtype)        # one weight-version check per forward
-        y = self.run_stem(video, pk)
+        y = self.run_stem(video, pk, video_slot)
         last = len(self._blocks) - 1
         for i in range(last + 1):
             y = self.run_block(i, y, pk, pool=(x_len, B, T) if i == last else None)

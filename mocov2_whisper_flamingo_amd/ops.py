@@ -289,9 +289,19 @@ def stem_stats_slabs(video):
     return torch.empty((2, parts, 64), dtype=torch.float32, device=video.device)
 
 
-def stem3d_fwd(video, weight, out_dtype, *, scale=None, shift=None, col_stats=None, frags=None):
+def store_u64(slot, value):
+    """slot: int64 tensor of one element on the GPU; ``value`` is written to it in stream order."""
+    _need_cuda(slot)
+    if slot.dtype != torch.int64 or slot.numel() != 1:
+        raise ValueError("store_u64 expects a one-element int64 tensor")
+    check(_lib.load().avsr_store_u64(_stream(), slot.data_ptr(), int(value)), "avsr_store_u64")
+
+
+def stem3d_fwd(video, weight, out_dtype, *, scale=None, shift=None, col_stats=None, frags=None, video_slot=None):
     """video [B,T,3,H,W] fp32 contiguous -> NHWC [B*T,OH,OW,64]; weight = stem_pack_weight(w);
-    frags = stem_pack_frags(weight) selects the MFMA kernel for bf16 outputs."""
+    frags = stem_pack_frags(weight) selects the MFMA kernel for bf16 outputs.
+    video_slot: one-element int64 GPU tensor; the kernel reads the input's address from it when it runs (store_u64)
+    and ``video`` only gives the shape - the launch can be recorded once and replayed on other batches in place."""
     lib = _lib.load()
     _need_cuda(video, weight)
     if video.dtype != torch.float32 or not video.is_contiguous() or weight.dtype != torch.float32:
@@ -302,6 +312,14 @@ def stem3d_fwd(video, weight, out_dtype, *, scale=None, shift=None, col_stats=No
     OH, OW = (H + 6 - 3) // 2 + 1, (W + 6 - 3) // 2 + 1
     out = torch.empty((B * T, OH, OW, 64), dtype=out_dtype, device=video.device)
     cs = col_stats or (None, None)
+    if video_slot is not None:
+        _need_cuda(video_slot)
+        if video_slot.dtype != torch.int64 or video_slot.numel() != 1 or video.data_ptr() % 16:
+            raise ValueError("video_slot must be a one-element int64 tensor and the video 16-byte aligned")
+        check(lib.avsr_stem3d_fwd_indirect(_stream(), _DT[out_dtype], video_slot.data_ptr(), weight.data_ptr(), _p(frags),
+                                           out.data_ptr(), _p(scale), _p(shift), _p(cs[0]), _p(cs[1]), B, T, H, W),
+              "avsr_stem3d_fwd_indirect")
+        return out
     check(lib.avsr_stem3d_fwd(_stream(), _DT[out_dtype], video.data_ptr(), weight.contiguous().data_ptr(), _p(frags), out.data_ptr(),
                               _p(scale), _p(shift), _p(cs[0]), _p(cs[1]), B, T, H, W), "avsr_stem3d_fwd")
     return out

@@ -540,6 +540,28 @@ def test_stem_mfma(dev, H, W, train):
     assert rel_err(y, y2) < 2e-2
 
 
+def test_stem_reads_its_input_through_a_device_word(dev):
+    """avsr_stem3d_fwd_indirect: the video's address comes from a device word when the kernel runs - same bits as the
+    direct call, whichever batch the word names; the forms that cannot take the indirection say so."""
+    g = torch.Generator().manual_seed(77)
+    B, T, H, W = 2, 5, 24, 32
+    vids = [torch.randn(B, T, 3, H, W, generator=g).to(dev) for _ in range(2)]
+    wp = ops.stem_pack_weight((torch.randn(64, 3, 5, 3, 3, generator=g) * 0.1).to(dev))
+    fr = ops.stem_pack_frags(wp)
+    slot = torch.zeros(1, dtype=torch.int64, device=dev)
+    for v in vids:
+        cs, cs2 = ops.stem_stats_slabs(v), ops.stem_stats_slabs(v)
+        want = ops.stem3d_fwd(v, wp, torch.bfloat16, col_stats=(cs[0], cs[1]), frags=fr)
+        ops.store_u64(slot, v.data_ptr())
+        got = ops.stem3d_fwd(vids[0], wp, torch.bfloat16, col_stats=(cs2[0], cs2[1]), frags=fr, video_slot=slot)
+        assert torch.equal(got, want) and torch.equal(cs, cs2)
+    assert slot.item() == vids[1].data_ptr()
+    with pytest.raises(ops._lib.AvsrHipError):                    # the direct fp32 kernel has no indirect form
+        ops.stem3d_fwd(vids[0], wp, torch.float32, video_slot=slot)
+    with pytest.raises(ValueError):
+        ops.stem3d_fwd(vids[0], wp, torch.bfloat16, frags=fr, video_slot=torch.zeros(2, dtype=torch.int64, device=dev))
+
+
 @pytest.mark.parametrize("nparts,C", [(5, 64), (33, 100), (793, 128), (2930, 64), (2930, 256), (5860, 200), (9000, 256)])
 def test_bn_finalize_slabs(dev, nparts, C):
     """Training-mode BN statistics from [parts, C] partial-sum slabs (direct, single-launch and two-stage paths)."""
