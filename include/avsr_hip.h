@@ -102,6 +102,27 @@ typedef struct {
      * very wide product (the vocabulary head) get every row's log-sum-exp without reading the product back:
      * avsr_head_loss_fwd(..., row_part, n_parts). */
     float* row_part;
+    /* A LayerNorm folded into the two products around it (HF modeling_whisper.py WhisperEncoderLayer.forward:
+     * self_attn_layer_norm -> q/k/v_proj, final_layer_norm -> fc1; dense unbatched bf16 products, N % 8 == 0,
+     * alpha == 1, all NULL / 0 = off).  The product that WRITES the LayerNorm's input (fp32 C with a residual,
+     * no activation) sets ln_out and copy_bf16: besides C it stores a bf16 copy of the rows (row stride ld_copy)
+     * and ln_out[(tile * M + m) * 2 + {0, 1}] = {sum, sum of squares} of row m over the columns of 128-column
+     * tile `tile` (ceil(N / 128) tiles).  The product that READS the normalised rows takes that copy as A, a weight
+     * whose columns are pre-multiplied by the LayerNorm's gain as B, and sets ln_in (= the other launch's ln_out),
+     * ln_parts (its tile count, at most 10), ln_eps and ln_colsum[n] = sum_k B[n, k]; `bias` must already hold
+     * bias[n] + sum_k beta[k] W[n, k].  Its epilogue computes, before the activation,
+     *   rstd[m] * acc[m, n] - rstd[m] * mean[m] * ln_colsum[n] + bias[n],
+     * which is LayerNorm(A)[m, :] . W[n, :] + bias[n] with mean / rstd over A's K columns: the normalised tensor is
+     * never written or read.
+     * The fp32 rows themselves can live as TWO bf16 planes instead of an fp32 matrix: copy_bf16 = bf16(v) and
+     * copy_lo = bf16(v - copy_bf16) (together v to 2^-18 relative; same bytes as fp32, and the first plane IS the next
+     * product's operand, so the writing product stores nothing extra).  With copy_lo given C may be NULL; the
+     * residual of such a product is either `residual` (fp32) or residual_hi + residual_lo (two planes, row stride
+     * ld_res_planes; may alias the output planes: an in-place update).  ln_out NULL with planes / C given: no
+     * statistics (the last product of a chain, whose reader is not a folded LayerNorm). */
+    const float* ln_in; int64_t ln_parts; float ln_eps; const float* ln_colsum;
+    float* ln_out; void* copy_bf16; int64_t ld_copy;
+    void* copy_lo; const void* residual_hi; const void* residual_lo; int64_t ld_res_planes;
 } avsr_gemm_t;
 
 int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g);

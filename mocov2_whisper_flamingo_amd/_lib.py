@@ -31,6 +31,9 @@ class GemmDesc(_c.Structure):
         ("col_sum", _vp), ("col_sumsq", _vp), ("conv", ConvDesc),
         ("pre", _vp), ("ldp", _i64), ("mul_gelu_grad_of", _vp), ("ld_aux", _i64), ("p_drop", _f32), ("seed", _u64),
         ("seed_delta", _vp), ("row_part", _vp),
+        ("ln_in", _vp), ("ln_parts", _i64), ("ln_eps", _f32), ("ln_colsum", _vp),
+        ("ln_out", _vp), ("copy_bf16", _vp), ("ld_copy", _i64),
+        ("copy_lo", _vp), ("residual_hi", _vp), ("residual_lo", _vp), ("ld_res_planes", _i64),
     ]
 
 

@@ -22,6 +22,11 @@ struct GemmP {
     void* pre; long ldp; const void* aux; long ldaux; float p_drop; unsigned long long seed; int ext;
     const unsigned long long* seed_delta;
     float* row_part;                        // [tiles of 128 columns][M][4]: per-row {max, sum exp, sum} of a tile (EXT)
+    // LayerNorm folded into the products on either side of it (EXT == 2 reads, EXT == 3 writes)
+    const float* ln_in; int ln_parts; float ln_eps;     // [ln_parts][M][2]: per-row {sum, sum of squares} of A's row, by 128-column tile
+    float* ln_out; void* copy; long ldcopy;             // the same for the stored rows of C, and a bf16 copy of them
+    void* copy_lo;                                      // bf16(value - copy): copy + copy_lo carry the fp32 row to 2^-18
+    const void* res_hi; const void* res_lo; long ldrp;  // a residual kept as such a pair of bf16 planes
 };
 
 // Block id -> (tile_m, tile_n).  Blocks are dealt round-robin over the 8 XCDs;
@@ -166,9 +171,16 @@ __device__ __forceinline__ void stats_quad(const GemmP& p, f32x4 s, f32x4 s2, in
 // RESPF (products with a residual operand): the residual rows of a pass are requested before the pass's LDS staging and
 // used from registers - in the rolled row loop every iteration would wait for its own residual load, eight to ten exposed
 // memory latencies per tile; the row loop of these instantiations is unrolled instead (2 or 4 iterations).
-template <int BN_, typename OutT, int ACT, bool CONV, int MI, bool EXT = false, bool RESPF = false>
+// EXT: 0 = plain, 1 = extended (second output, dropout, GELU gradient, row log-sum-exp partials),
+// 2 = the A operand is the un-normalised input of a LayerNorm whose gain is folded into B: a row's mean and 1 / std come
+//     from per-tile partial sums (lnrow: {rstd, -rstd * mean} per tile row, staged in LDS at kernel entry) and
+//     out = rstd * acc - rstd * mean * colsum(B)[n] + bias'[n]  (the `scale` slot holds colsum(B), `bias` holds bias'),
+// 3 = fp32 output with residual that is the input of the NEXT LayerNorm: also stores a bf16 copy of the rows and their
+//     per-tile {sum, sum of squares} (what an EXT == 2 product reads).
+template <int BN_, typename OutT, int ACT, bool CONV, int MI, int EXT = 0, bool RESPF = false>
 __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][BN_ / 32], char* lds, const float* sb,
-                                              int m0, int n0, int tm, long cbase, int lane, int wave) {
+                                              int m0, int n0, int tm, long cbase, int lane, int wave,
+                                              const float* lnrow = nullptr) {
     constexpr int NJ = BN_ / 32, LDT = BN_ + 4, CG = BN_ / 8, RS = 256 / CG;
     // a pass moves SUBS 16-row sub-tiles of each wave (2 x SUBS x 16 tile rows) through the LDS tile
     constexpr int SUBS = (MI % 2 == 0) ? 2 : 1, NPASS = MI / SUBS, PROWS = 2 * SUBS * 16;
@@ -190,11 +202,11 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
     }
     const bool full = p.vec_ok && n + 7 < p.N;
     // 16-byte accesses to the second output and the saved GELU inputs: the host checked their alignment
-    const bool ext_vec = EXT && p.ext == 2;
+    const bool ext_vec = EXT == 1 && p.ext == 2;
     const bool has_res = p.res != nullptr;
     const bool stats = p.csum != nullptr;
     uint64_t run_seed = 0;
-    if constexpr (EXT) run_seed = avsr_run_seed(p.seed, (const uint64_t*)p.seed_delta);
+    if constexpr (EXT == 1) run_seed = avsr_run_seed(p.seed, (const uint64_t*)p.seed_delta);
     constexpr int NIT = (PROWS + RS - 1) / RS, UNR = RESPF ? NIT : 1;
     constexpr int RW = sizeof(OutT) == 4 ? 2 : 1;       // 16-byte words of residual per thread and row
     f32x4 rpf[RESPF ? NIT * RW : 1];
@@ -206,9 +218,14 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                 const int lr = r0 + it * RS;
                 const int m = m0 + (lr / (SUBS * 16)) * (MI * 16) + h * (SUBS * 16) + (lr % (SUBS * 16));
                 if ((PROWS % RS == 0 || lr < PROWS) && m < p.M && full) {
-                    const OutT* rp = (const OutT*)p.res + (long)(p.res_period > 0 ? m % p.res_period : m) * p.ldr + n;
+                    if (EXT == 3 && !has_res) {         // the residual as two bf16 planes
+                        rpf[it * RW] = *(const f32x4*)((const bf16_t*)p.res_hi + (long)m * p.ldrp + n);
+                        rpf[it * RW + RW - 1] = *(const f32x4*)((const bf16_t*)p.res_lo + (long)m * p.ldrp + n);
+                    } else {
+                        const OutT* rp = (const OutT*)p.res + (long)(p.res_period > 0 ? m % p.res_period : m) * p.ldr + n;
 #pragma unroll
-                    for (int w = 0; w < RW; ++w) rpf[it * RW + w] = *(const f32x4*)((const char*)rp + 16 * w);
+                        for (int w = 0; w < RW; ++w) rpf[it * RW + w] = *(const f32x4*)((const char*)rp + 16 * w);
+                    }
                 }
             }
         }
@@ -231,7 +248,7 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
             float pv[8], av[8];                 // EXT: the second output's values / the saved GELU inputs
             uint32_t draws[8];                  // EXT: the eight elements' dropout draws (two generator calls)
             bool draws_ok = false;
-            if constexpr (EXT) {
+            if constexpr (EXT == 1) {
                 const uint64_t i0 = (uint64_t)((long)m * p.N + n);
                 if (p.p_drop > 0.f && (i0 & 3) == 0) {
                     avsr_rand4(run_seed, i0 >> 2, draws);
@@ -239,7 +256,7 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                     draws_ok = true;
                 }
             }
-            if constexpr (EXT) {
+            if constexpr (EXT == 1) {
                 if (p.aux) {
                     const OutT* ap = (const OutT*)p.aux + (long)m * p.ldaux + n;
                     if (full && ext_vec) {
@@ -258,14 +275,21 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                     }
                 }
             }
+            float ln_r = 0.f, ln_nrm = 0.f;     // EXT == 2: this row's 1 / std and -mean / std
+            if constexpr (EXT == 2) {
+                const float2 rs = ((const float2*)lnrow)[m - m0];
+                ln_r = rs.x; ln_nrm = rs.y;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float x = fmaf(v[e], sc[e], bi[e]);
+                float x;
+                if constexpr (EXT == 2) x = fmaf(v[e], ln_r, fmaf(ln_nrm, sc[e], bi[e]));
+                else x = fmaf(v[e], sc[e], bi[e]);
                 if (stats) { s1[e] += x; s2[e] = fmaf(x, x, s2[e]); }
-                if constexpr (EXT) pv[e] = x;   // second output: the value before the activation / gate
+                if constexpr (EXT == 1) pv[e] = x;   // second output: the value before the activation / gate
                 if (ACT == AVSR_ACT_GELU) x = gelu_erf_fast(x);
                 else if (ACT == AVSR_ACT_RELU) x = fmaxf(x, 0.f);
-                if constexpr (EXT) {
+                if constexpr (EXT == 1) {
                     if (p.aux) x *= gelu_erf_grad_fast(av[e]);
                     if (p.p_drop > 0.f) {
                         const bool keep = draws_ok ? avsr_bits_keep(draws[e], p.p_drop)
@@ -275,7 +299,7 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                 }
                 v[e] = x;
             }
-            if constexpr (EXT && BN_ == 128) {
+            if constexpr (EXT == 1 && BN_ == 128) {
                 if (p.row_part) {               // log-sum-exp partials of this row over the tile's valid columns
                     float mx = -INFINITY, sx = 0.f;
 #pragma unroll
@@ -292,7 +316,7 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                         *(f32x4*)(p.row_part + ((long)(n0 / BN_) * p.M + m) * 4) = (f32x4){mx, se, sx, 0.f};
                 }
             }
-            if constexpr (EXT) {
+            if constexpr (EXT == 1) {
                 if (p.pre) {
                     OutT* pp = (OutT*)p.pre + cbase + (long)m * p.ldp + n;
                     if (full && ext_vec) {
@@ -311,7 +335,7 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                     }
                 }
             }
-            if constexpr (EXT) {
+            if constexpr (EXT == 1) {
                 if (p.C == nullptr) continue;   // statistics-only pass: the column sums are all this launch produces
             }
             OutT* cp = (OutT*)p.C + cbase + (long)m * p.ldc + n;
@@ -331,12 +355,28 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = fmaf(g, v[e], (float)rv[e]);
                     }
+                } else if constexpr (EXT == 3) {
+                    const bf16x8 hi = __builtin_bit_cast(bf16x8, rpf[it * RW]), lo = __builtin_bit_cast(bf16x8, rpf[it * RW + RW - 1]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)hi[e] + (float)lo[e];
                 }
                 if (ACT == AVSR_ACT_RELU_AFTER_RESIDUAL) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                if constexpr (sizeof(OutT) == 4) {
+                if constexpr (EXT == 3) {
+                    if (p.C) {
+                        *(f32x4*)cp = (f32x4){v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                    }
+                    if (p.copy) {               // the rows as the next product's operand (+ what the rounding dropped)
+                        bf16x8 o, l;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { o[e] = (bf16_t)v[e]; l[e] = (bf16_t)(v[e] - (float)o[e]); }
+                        *(bf16x8*)((bf16_t*)p.copy + (long)m * p.ldcopy + n) = o;
+                        if (p.copy_lo) *(bf16x8*)((bf16_t*)p.copy_lo + (long)m * p.ldcopy + n) = l;
+                    }
+                } else if constexpr (sizeof(OutT) == 4) {
                     *(f32x4*)cp = (f32x4){v[0], v[1], v[2], v[3]};
                     *(f32x4*)(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                 } else {
@@ -345,6 +385,9 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
                     *(bf16x8*)cp = o;
                 }
+            } else if constexpr (EXT == 3) {    // (the host admits whole 8-column groups only: nothing of this row here)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -355,6 +398,13 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
                         cp[e] = from_f32<OutT>(x);
                     }
                 }
+            }
+            if (EXT == 3 && BN_ == 128 && p.ln_out) {    // the 16 lanes of a row hold its 128 columns of this tile
+                float sx = 0.f, sq = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sx += v[e]; sq = fmaf(v[e], v[e], sq); }
+                sx = row16_sum(sx); sq = row16_sum(sq);
+                if (cg == 0) ((float2*)p.ln_out)[(long)(n0 / BN_) * p.M + m] = make_float2(sx, sq);
             }
         }
     }
@@ -390,14 +440,26 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
     }
 }
 
-template <int BN_, typename OutT, bool CONV, int MI, bool EXT = false>
+template <int BN_, typename OutT, bool CONV, int MI, int EXT = 0>
 __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][BN_ / 32], char* lds, const float* sb,
-                                              int m0, int n0, int tm, long cbase, int lane, int wave) {
-    if constexpr (EXT) {                        // instantiations of their own: the plain kernels' code is untouched
+                                              int m0, int n0, int tm, long cbase, int lane, int wave,
+                                              const float* lnrow = nullptr) {
+    if constexpr (EXT == 1) {                   // instantiations of their own: the plain kernels' code is untouched
         if (p.act == AVSR_ACT_GELU)
-            epilogue_body<BN_, OutT, AVSR_ACT_GELU, CONV, MI, true>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+            epilogue_body<BN_, OutT, AVSR_ACT_GELU, CONV, MI, 1>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
         else
-            epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV, MI, true>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+            epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV, MI, 1>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+        return;
+    }
+    if constexpr (EXT == 2) {
+        if (p.act == AVSR_ACT_GELU)
+            epilogue_body<BN_, OutT, AVSR_ACT_GELU, CONV, MI, 2>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave, lnrow);
+        else
+            epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV, MI, 2>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave, lnrow);
+        return;
+    }
+    if constexpr (EXT == 3) {
+        epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV, MI, 3, true>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
         return;
     }
 #ifndef G_NO_RESPF
@@ -452,6 +514,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][B
 #define G_NST_SWITCH_TILES 1000
 #endif
 #define G_NUM_CU 256
+#define G_LN_MAXP 10                        // 128-column tiles of a folded LayerNorm's rows (d_model <= 1280)
 #ifndef G_BM160
 #define G_BM160 1
 #endif
@@ -492,17 +555,18 @@ extern "C" int avsr_debug_read_stamps(unsigned long long* out) {
 #define STAMP(i)
 #endif
 
-template <int BN_, int G_NST, int BM_ = G_BM> constexpr int gemm_lds_bytes() {
+template <int BN_, int G_NST, int BM_ = G_BM, int EXT = 0> constexpr int gemm_lds_bytes() {
     constexpr int stage = (BM_ / 8 + BN_ / 8) * 1024;
     constexpr int epi = (64 * (BN_ + 4) + 8 * BN_) * 4;
-    return (G_NST * stage > epi ? G_NST * stage : epi) + 2 * BN_ * 4;     // + the tile's scale / bias columns
+    // + the tile's scale / bias columns (+ the tile rows' LayerNorm factors)
+    return (G_NST * stage > epi ? G_NST * stage : epi) + 2 * BN_ * 4 + (EXT == 2 ? BM_ * 8 : 0);
 }
 
 // CONV: 0 = dense operands, 1 = implicit-GEMM convolution with per-lane (tap, channel) cursors (any channel count),
 // 2 = convolution whose channel count is a multiple of the K-step: a K-step lies inside ONE filter tap, so the tap is
 // a scalar, a lane keeps one byte offset per piece (its pixel) and a bit per tap (inside the image or padding), and
 // the K loop carries no per-lane index arithmetic beyond one 64-bit add and the zero-page select.
-template <int BN_, int G_NST, int CONV, typename OutT, int BM_ = G_BM, bool EXT = false>
+template <int BN_, int G_NST, int CONV, typename OutT, int BM_ = G_BM, int EXT = 0>
 // Single-stage instantiations: dense operands at three workgroups per CU (168 registers, no spills) - four (128
 // registers) is faster for some products run alone, but with two or three streams sharing the chip the step is
 // 2.5 % faster at three; the convolution form stays at four (no difference in the step, faster alone).
@@ -543,6 +607,15 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : 
         const int nc = min(n0 + t, p.N - 1);
         sb[t] = p.scale ? p.scale[nc] * p.alpha : p.alpha;
         sb[BN_ + t] = p.bias ? p.bias[nc] : 0.f;
+    }
+    float* lnrow = sb + 2 * BN_;
+    // EXT == 2: the partial sums of the tile's rows are requested now, all at once, and folded after the K loop
+    float2 lnp[EXT == 2 ? G_LN_MAXP : 1];
+    if constexpr (EXT == 2) {
+        const int m = min(m0 + min(t, BM_ - 1), p.M - 1);
+#pragma unroll
+        for (int i = 0; i < G_LN_MAXP; ++i)
+            lnp[i] = i < p.ln_parts ? ((const float2*)p.ln_in)[(long)i * p.M + m] : make_float2(0.f, 0.f);
     }
 
     // ---- DMA sources ----------------------------------------------------------
@@ -726,7 +799,20 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : 
         wait_vmcnt<0>();                        // drain the re-loaded steps before the LDS is reused
     }
     STAMP(3);
-    epilogue_tile<BN_, OutT, CONV != 0, MI, EXT>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+    if constexpr (EXT == 2) {
+        // LayerNorm factors of the tile's rows, partial sums folded in a fixed order (the epilogue's first barrier
+        // comes before its first read of them)
+        if (t < BM_) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < G_LN_MAXP; ++i) { s += lnp[i].x; q += lnp[i].y; }
+            const float inv = 1.0f / (float)p.K;
+            const float mean = s * inv;
+            const float r = rsqrtf(fmaxf(fmaf(-mean, mean, q * inv), 0.f) + p.ln_eps);
+            ((float2*)lnrow)[t] = make_float2(r, -r * mean);
+        }
+    }
+    epilogue_tile<BN_, OutT, CONV != 0, MI, EXT>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave, lnrow);
 #ifdef GEMM_STAMPS
     STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -841,7 +927,8 @@ extern "C" int64_t avsr_gemm_stats_parts(int in_dtype, int64_t M) {
 extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     if (!g || !g->A || !g->B) return AVSR_EINVAL;
     // C == NULL: a statistics-only pass (column sums without the product itself; dense bf16 products only)
-    if (!g->C && !(g->col_sum && g->in_dtype == AVSR_BF16 && !g->pre && !g->residual)) return AVSR_EINVAL;
+    if (!g->C && !(g->col_sum && g->in_dtype == AVSR_BF16 && !g->pre && !g->residual) && !(g->copy_bf16 && g->copy_lo))
+        return AVSR_EINVAL;
     if (g->M <= 0 || g->N <= 0 || g->K <= 0 || g->batch <= 0) return AVSR_EINVAL;
     if (g->M > 0x7fffffff || g->N > 0x7fffffff || g->K > 0x7fffffff) return AVSR_EUNSUPPORTED;
     if (g->in_dtype != AVSR_F32 && g->in_dtype != AVSR_BF16) return AVSR_EINVAL;
@@ -882,7 +969,37 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     p.p_drop = g->p_drop; p.seed = g->seed; p.seed_delta = (const unsigned long long*)g->seed_delta;
     p.row_part = g->row_part;
     if (g->row_part && (!bf || g->act != AVSR_ACT_NONE || !aligned_to(g->row_part, 16))) return AVSR_EUNSUPPORTED;
-    p.ext = (g->pre || g->mul_gelu_grad_of || g->p_drop > 0.f || !g->C || g->row_part) ? 1 : 0;
+    p.ext = (g->pre || g->mul_gelu_grad_of || g->p_drop > 0.f || (!g->C && !g->copy_lo) || g->row_part) ? 1 : 0;
+    // LayerNorm folded into the products around it: 2 = this product's A rows are normalised in the epilogue,
+    // 3 = this product's stored rows leave their statistics and a bf16 copy for such a product
+    const int lnmode = g->ln_in ? 2 : ((g->ln_out || g->copy_bf16 || g->residual_hi) ? 3 : 0);
+    p.ln_in = g->ln_in; p.ln_parts = (int)g->ln_parts; p.ln_eps = g->ln_eps;
+    p.ln_out = g->ln_out; p.copy = g->copy_bf16; p.ldcopy = g->ld_copy; p.copy_lo = g->copy_lo;
+    p.res_hi = g->residual_hi; p.res_lo = g->residual_lo; p.ldrp = g->ld_res_planes;
+    if (lnmode) {
+        if (g->ln_in && lnmode != 2) return AVSR_EUNSUPPORTED;
+        if (g->ln_in && (g->ln_out || g->copy_bf16 || g->residual_hi)) return AVSR_EUNSUPPORTED;
+        if (!bf || conv || g->batch != 1 || p.ext || g->col_sum || g->gate || g->N % 8 || g->alpha != 1.0f)
+            return AVSR_EUNSUPPORTED;
+        if (lnmode == 2) {
+            // out = rstd * (A B^T) - rstd * mean * ln_colsum + bias: the column sums ride in the scale slot
+            if (!g->ln_colsum || g->scale || g->residual || g->out_dtype != AVSR_BF16 || g->ln_parts <= 0 ||
+                g->ln_parts > G_LN_MAXP || (g->act != AVSR_ACT_NONE && g->act != AVSR_ACT_GELU) || !aligned_to(g->ln_in, 8))
+                return AVSR_EUNSUPPORTED;
+            p.scale = g->ln_colsum;
+        } else {
+            // exactly one residual (fp32, or a pair of bf16 planes); C and / or the bf16 planes as outputs
+            if ((g->residual != nullptr) == (g->residual_hi != nullptr) || (g->residual_hi && !g->residual_lo) ||
+                g->res_period > 0 || g->out_dtype != AVSR_F32 || g->act != AVSR_ACT_NONE || g->scale)
+                return AVSR_EUNSUPPORTED;
+            if (g->residual_hi && (!aligned_to(g->residual_hi, 16) || !aligned_to(g->residual_lo, 16) ||
+                                   g->ld_res_planes % 8 || g->ld_res_planes < g->N)) return AVSR_EUNSUPPORTED;
+            if (g->copy_bf16 && (!aligned_to(g->copy_bf16, 16) || !aligned_to(g->copy_lo, 16) || g->ld_copy % 8 ||
+                                 g->ld_copy < g->N)) return AVSR_EUNSUPPORTED;
+            if ((g->ln_out && !g->copy_bf16) || (g->copy_lo && !g->copy_bf16) || !aligned_to(g->ln_out, 8) ||
+                (!g->C && !(g->copy_bf16 && g->copy_lo))) return AVSR_EUNSUPPORTED;
+        }
+    }
     if (p.ext) {
         const size_t osz_ = g->out_dtype == AVSR_BF16 ? 2 : 4;
         if ((!g->pre || (aligned_to(g->pre, 16) && (g->ldp * osz_) % 16 == 0)) &&
@@ -901,14 +1018,14 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     int bn = (bf && g->N <= 64 && !p.ext) ? 64 : 128;
     // A grid of a few dozen 128 x 128 tiles leaves most CUs idle while each busy one grinds through its tile's whole
     // K loop at one CU's MFMA rate: 64 x 64 tiles put four times as many CUs to work on a quarter of the tile each.
-    const bool small = bf && !conv && !g->col_sum && g->batch == 1 && bn == 128 && !g->row_part &&     // row_part: 128-wide tiles
+    const bool small = bf && !conv && !g->col_sum && g->batch == 1 && bn == 128 && !g->row_part && !lnmode &&  // row_part, ln: 128-wide tiles
                        ((g->M + 127) / 128) * ((g->N + 127) / 128) <= G_SMALL_TILES;
     if (small) bn = 64;
     // Row tile: 128, or 96 where that fills the CUs' last round much better (M = 12000, N = 768: 564 tiles leave a
     // quarter of the chip idle while 52 CUs run a third tile; 750 tiles of 96 rows are 2.93 per CU).
     int bm = G_BM;
     if (small) bm = 64;
-    if (bf && !conv && !g->col_sum && bn == 128 && !p.ext) {
+    if (bf && !conv && !g->col_sum && bn == 128 && !p.ext && lnmode != 2) {
         // batched products (the Whisper stem convolutions, one batch per clip) count every batch's tiles
         const long tn = ((p.N + 127) / 128) * std::max<long>(1, g->batch);
         const long t128 = ((p.M + 127) / 128) * tn, t96 = ((p.M + 95) / 96) * tn;
@@ -916,7 +1033,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
             const long rounds = (t + G_NUM_CU - 1) / G_NUM_CU;
             return (double)M * tnn / ((double)rounds * G_NUM_CU * rows);
         };
-        if (t96 >= G_T96_MIN_TILES && fill(t96, 96, p.M, tn) > G_FILL_RATIO * fill(t128, 128, p.M, tn)) bm = 96;
+        if (!lnmode && t96 >= G_T96_MIN_TILES && fill(t96, 96, p.M, tn) > G_FILL_RATIO * fill(t128, 128, p.M, tn)) bm = 96;
 #if G_BM160
         // 160-row tiles where they save a whole round over 128-row ones (M = 12000, N = 768: 450 tiles in two rounds
         // instead of 564 in three; double-buffered, two workgroups per CU: alone 88 -> 68 us at K = 3072, 35 -> 31 us at
@@ -932,7 +1049,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     // workgroup per CU runs at a fifth of the CU's matrix rate either way, which is what bounds these launches).
     bool one_round160 = false;
 #ifndef G_NO_ONE_ROUND160
-    if (bf && bn == 128 && !p.ext && g->batch == 1 && !small) {
+    if (bf && bn == 128 && !p.ext && g->batch == 1 && !small && !lnmode) {
         const long tn = (p.N + 127) / 128;
         const long t128 = ((p.M + 127) / 128) * tn, t160 = ((p.M + 159) / 160) * tn;
         const bool fast_ok = conv && g->conv.C % G_BK == 0 && g->conv.KH * g->conv.KW <= 32 &&
@@ -943,10 +1060,10 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     // 256-row tiles (a wave owns 128 x 64: a quarter less LDS traffic per MFMA) pay off where K is long and there are
     // at least two such tiles per CU: 4096^3 918 -> 1140 TFLOP/s, 8192^3 1066 -> 1161; a loss on every product of this
     // network (M = 12000, K = 768: 846 tiles on 512 resident slots, and prologue + epilogue of a 12-step tile weigh more).
-    if (bf && !conv && !g->col_sum && bn == 128 && g->batch == 1 && bm == G_BM && !p.ext &&
+    if (bf && !conv && !g->col_sum && bn == 128 && g->batch == 1 && bm == G_BM && !p.ext && !lnmode &&
         ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 2 * G_NUM_CU && p.K >= 2048) bm = 256;
 #ifdef G_TUNE_ENV
-    if (bf && !conv && !g->col_sum && bn == 128 && !p.ext && !small) {          // tuning builds only
+    if (bf && !conv && !g->col_sum && bn == 128 && !p.ext && !small && !lnmode) {          // tuning builds only
         if (const char* e = getenv("AVSR_FORCE_BM")) { bm = atoi(e); one_round160 = false; }
     }
 #endif
@@ -988,7 +1105,15 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     do {                                                                                                       \
         static avsr_dev_flags attr_set;                                                                        \
         constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV, BMV>();                                            \
-        auto kfn = gemm_bf16_kernel<BNV, NSTV, 0, OT, BMV, true>;                                              \
+        auto kfn = gemm_bf16_kernel<BNV, NSTV, 0, OT, BMV, 1>;                                                 \
+        if (!avsr_allow_lds((const void*)kfn, lds_bytes, attr_set)) return AVSR_EHIP;                          \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
+    } while (0)
+#define LAUNCHLN(NSTV, OT, BMV, MODE)                                                                          \
+    do {                                                                                                       \
+        static avsr_dev_flags attr_set;                                                                        \
+        constexpr int lds_bytes = gemm_lds_bytes<128, NSTV, BMV, MODE>();                                      \
+        auto kfn = gemm_bf16_kernel<128, NSTV, 0, OT, BMV, MODE>;                                              \
         if (!avsr_allow_lds((const void*)kfn, lds_bytes, attr_set)) return AVSR_EHIP;                          \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
     } while (0)
@@ -1003,7 +1128,15 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     // single-stage ones its extra per-lane state spills inside the K loop (measured: half the rate).
     const bool conv_fast = bf && conv && g->conv.C % G_BK == 0 && g->conv.KH * g->conv.KW <= 32 &&
                            (g->M / ((int64_t)g->conv.OH * g->conv.OW)) * g->conv.H * g->conv.W * g->conv.C * 2 < (1ll << 31);
-    if (bf && p.ext) {
+    if (lnmode == 2) {
+        // the tile shapes the encoder's QKV / fc1 products take without the fold (single stage on full grids)
+        if (ntiles >= G_NST_SWITCH_TILES) LAUNCHLN(1, bf16_t, 128, 2); else LAUNCHLN(2, bf16_t, 128, 2);
+    } else if (lnmode == 3) {
+        if (!p.vec_ok) return AVSR_EUNSUPPORTED;
+        if (bm == 160) LAUNCHLN(G_BM160_NST, float, 160, 3);
+        else if (ntiles >= G_NST_SWITCH_TILES) LAUNCHLN(1, float, 128, 3);
+        else LAUNCHLN(2, float, 128, 3);
+    } else if (bf && p.ext) {
         // extended epilogue: a second set of instantiations, restricted to the tile shapes the trainable tail uses
         const bool single = ntiles >= G_NST_SWITCH_TILES;
         if (small) { if (of) LAUNCHX(64, 4, float, 64); else LAUNCHX(64, 4, bf16_t, 64); }
@@ -1036,6 +1169,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
 #undef LAUNCHBM
 #undef LAUNCHBMC
 #undef LAUNCHX
+#undef LAUNCHLN
 #undef LAUNCH_CV_OT
 #undef LAUNCH_FAST_OT
     return avsr_launch_status();

@@ -41,10 +41,19 @@ def _need_cuda(*ts):
 
 
 def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NONE, residual=None,
-            res_period=0, gate=None, alpha=1.0, col_stats=None, conv=None, M=None, stats_only=False, row_part=None):
+            res_period=0, gate=None, alpha=1.0, col_stats=None, conv=None, M=None, stats_only=False, row_part=None,
+            ln_out=None, ln_in=None, planes_out=None, planes_res=None, no_out=False):
     """out[m,n] = epi(sum_k a[m,k] b[n,k]).  a: [M,K] or [batch,M,K]; b: [N,K] or [batch,N,K].
     conv = (H, W, C, KH, KW, stride, pad_h, pad_w, OH, OW): a is an NHWC image batch, M = n_img*OH*OW.
-    ``stats_only``: fill ``col_stats`` and store no product (returns None)."""
+    ``stats_only``: fill ``col_stats`` and store no product (returns None).
+    A LayerNorm between two products, folded into them (see ``ln_fold_weights``):
+    ``ln_out`` = (parts [ceil(N/128), M, 2] fp32, copy [M, N] bf16) on the product that writes the LayerNorm's input
+    (fp32 ``out`` with ``residual``): also stores the rows' per-tile {sum, sum of squares} and their bf16 copy;
+    ``ln_in`` = (parts, colsum [N] fp32, eps) on the product that reads the normalised rows: ``a`` is that bf16 copy,
+    ``b`` / ``bias`` come from ``ln_fold_weights``.
+    ``planes_out`` = (hi, lo) bf16 [M, N]: the fp32 result as hi = bf16(v), lo = bf16(v - hi) (with ``no_out`` instead of
+    ``out``; ``ln_out`` = (parts, None) then adds the statistics); ``planes_res`` = (hi, lo): the residual in that form
+    (may be the same tensors as ``planes_out``)."""
     lib = _lib.load()
     _need_cuda(a, b, out, bias, scale, residual, gate)
     d = GemmDesc()
@@ -74,12 +83,12 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
     if stats_only:
         if col_stats is None or out is not None or residual is not None:
             raise ValueError("a statistics-only product takes col_stats and neither out nor residual")
-    elif out is None:
+    elif out is None and not no_out:
         shape = (batch, Mv, N) if (a.dim() == 3 and conv is None) else (Mv, N)
         out = torch.empty(shape, dtype=odt, device=a.device)
     if out is not None and out.stride(-1) != 1:
         raise ValueError("out must be row-major")
-    d.in_dtype, d.out_dtype = _dt(a), _DT[odt if out is None else out.dtype]
+    d.in_dtype, d.out_dtype = _dt(a), _DT[(torch.float32 if no_out else odt) if out is None else out.dtype]
     if b.dtype != a.dtype:
         raise TypeError("a and b dtypes differ")
     d.M, d.N, d.K = Mv, N, K
@@ -91,7 +100,7 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
     d.alpha = alpha
     d.scale, d.bias, d.act = _p(scale), _p(bias), act
     if residual is not None:
-        if residual.dtype != out.dtype or residual.stride(-1) != 1:
+        if residual.dtype != (torch.float32 if out is None else out.dtype) or residual.stride(-1) != 1:
             raise ValueError("residual must match the output dtype and be row-major")
         d.residual, d.ldr, d.res_period = residual.data_ptr(), residual.stride(-2), res_period
     d.gate = _p(gate)
@@ -101,6 +110,39 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
         if row_part.dtype != torch.float32 or not row_part.is_contiguous() or row_part.numel() < row_lse_parts(N) * Mv * 4:
             raise ValueError("row_part must be a contiguous fp32 buffer of row_lse_parts(N) * M * 4 floats")
         d.row_part = row_part.data_ptr()
+    def _plane(t):
+        if t.dtype != torch.bfloat16 or t.stride(-1) != 1 or t.dim() != 2 or t.shape[0] < Mv or t.shape[1] < N:
+            raise ValueError("a bf16 plane is a row-major [M, N] bf16 tensor")
+        _need_cuda(t)
+        return t
+    if planes_out is not None:
+        hi, lo = _plane(planes_out[0]), _plane(planes_out[1])
+        if hi.stride(0) != lo.stride(0):
+            raise ValueError("the two planes share one row stride")
+        d.copy_bf16, d.copy_lo, d.ld_copy = hi.data_ptr(), lo.data_ptr(), hi.stride(0)
+    if planes_res is not None:
+        hi, lo = _plane(planes_res[0]), _plane(planes_res[1])
+        if hi.stride(0) != lo.stride(0) or residual is not None:
+            raise ValueError("the two planes share one row stride, and replace `residual`")
+        d.residual_hi, d.residual_lo, d.ld_res_planes = hi.data_ptr(), lo.data_ptr(), hi.stride(0)
+    if ln_out is not None:
+        parts, copy = ln_out
+        if parts.dtype != torch.float32 or not parts.is_contiguous() or parts.numel() < row_lse_parts(N) * Mv * 2:
+            raise ValueError("ln_out = (fp32 [ceil(N/128), M, 2] contiguous, bf16 [M, N] row-major or None with planes_out)")
+        _need_cuda(parts)
+        d.ln_out = parts.data_ptr()
+        if copy is not None:
+            d.copy_bf16, d.ld_copy = _plane(copy).data_ptr(), copy.stride(-2)
+        elif planes_out is None:
+            raise ValueError("ln_out needs the bf16 copy of the rows (its second element, or planes_out)")
+    if ln_in is not None:
+        parts, colsum, eps = ln_in
+        n_parts = row_lse_parts(K)
+        if (parts.dtype != torch.float32 or not parts.is_contiguous() or parts.numel() < n_parts * Mv * 2
+                or colsum.dtype != torch.float32 or colsum.numel() != N or not colsum.is_contiguous()):
+            raise ValueError("ln_in = (fp32 [ceil(K/128), M, 2] contiguous, fp32 [N], eps)")
+        _need_cuda(parts, colsum)
+        d.ln_in, d.ln_parts, d.ln_eps, d.ln_colsum = parts.data_ptr(), n_parts, eps, colsum.data_ptr()
     if GEMM_PROFILE is None:
         check(lib.avsr_gemm_nt(_stream(), ctypes.byref(d)), "avsr_gemm_nt")
         return out
@@ -126,6 +168,21 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
         rec = rec + (e2, e3)
     GEMM_PROFILE.append(rec)
     return out
+
+
+def ln_fold_weights(weight, bias, gamma, beta, dtype=torch.bfloat16):
+    """LayerNorm(x; gamma, beta) @ weight^T + bias as a product on the UN-normalised x:
+        rstd * (x @ w_g^T) - rstd * mean * colsum + bias_b,
+    w_g = weight * gamma (rounded to ``dtype``: what the MFMA multiplies), colsum[n] = sum_k w_g[n, k] (of the rounded
+    values, so the mean's term cancels what the product accumulated), bias_b = bias + weight @ beta.
+    Returns (w_g, colsum, bias_b) for ``gemm_nt(..., ln_in=)``."""
+    w = weight.detach().float()
+    w_g = (w * gamma.detach().float()[None, :]).to(dtype).contiguous()
+    colsum = w_g.float().sum(1).contiguous()
+    bias_b = (w @ beta.detach().float())
+    if bias is not None:
+        bias_b = bias_b + bias.detach().float()
+    return w_g, colsum, bias_b.contiguous()
 
 
 def gemm_nt_splitk(a, b, S, out_dtype=None):

@@ -8,6 +8,7 @@ The encoder is frozen in the reference (models/av_net.py:25-26), so there is
 no backward here: ``WhisperEncoder.forward`` runs under ``no_grad``.
 """
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -96,10 +97,18 @@ class WhisperEncoder(nn.Module):
         self.attn_split = False
         self._attn_ws = ops.AttnWorkspace()     # the layers run one after another on one stream: one scratch for all
         self.attn_fp8 = False
+        # ln_fold (bf16 compute dtype, d_model a multiple of 128): the LayerNorms between an out-projection / fc2 and
+        # the QKV / fc1 product after it are not launched.  Between such products the fp32 residual stream lives as
+        # two bf16 planes (hi = bf16(x), lo = bf16(x - hi): the same bytes, x to 2^-18): the producing product's
+        # epilogue updates the planes in place and leaves the rows' per-tile {sum, sum of squares}; the consuming
+        # product multiplies the hi plane - the un-normalised rows - by gain-folded weights and normalises in its
+        # epilogue (ops.ln_fold_weights).  Per layer two launches and two passes over the stream less; rounding moves
+        # from LayerNorm's output to its input.
+        self.ln_fold = os.environ.get("AVSR_LN_FOLD", "1") != "0"
 
     # ---- weight packing -------------------------------------------------
     def _versions(self, dtype):
-        return (dtype, sum(p._version for p in self.parameters()), next(self.parameters()).data_ptr())
+        return (dtype, sum(p._version for p in self.parameters()), next(self.parameters()).data_ptr(), self.ln_fold)
 
     def _pack(self, dtype):
         """One-time (per weight version) repacking into what the kernels read:
@@ -135,6 +144,10 @@ class WhisperEncoder(nn.Module):
                 "wfc1": L.fc1.weight.detach().to(dtype).contiguous(), "bfc1": f32(L.fc1.bias),
                 "wfc2": L.fc2.weight.detach().to(dtype).contiguous(), "bfc2": f32(L.fc2.bias),
             })
+            if self.ln_fold and dtype == torch.bfloat16 and d % 128 == 0 and d <= 1280:
+                lw = pk["layers"][-1]
+                lw["qkv_ln"] = ops.ln_fold_weights(wqkv, bqkv, *lw["ln1"])
+                lw["fc1_ln"] = ops.ln_fold_weights(L.fc1.weight, L.fc1.bias, *lw["ln2"])
         self._packed = (key, pk)
         return pk
 
@@ -192,9 +205,40 @@ class WhisperEncoder(nn.Module):
                 raise ValueError("fp8 attention needs the bf16 compute dtype")
             use_mfma = "fp8"
         n_keep = Tn if rows is None else max(1, min(int(rows), Tn))
+        fold = "qkv_ln" in pk["layers"][0] if pk["layers"] else False
+        if fold:
+            eps = self.layers[0].self_attn_layer_norm.eps
+            xb = torch.empty((2, B * Tn, D), dtype=dtype, device=x.device)         # the stream's rows as hi / lo planes
+            planes = (xb[0], xb[1])
+            lnp = torch.empty((ops.row_lse_parts(D), B * Tn, 2), dtype=torch.float32, device=x.device)
+        have = False                    # the stream is in the planes (and lnp holds its row statistics), not in xs
+        last = len(pk["layers"]) - 1
         for li, lw in enumerate(pk["layers"]):
+            pruned = n_keep < Tn and li == last
+            if fold and not pruned:
+                if have:
+                    w_g, colsum, bias_b = lw["qkv_ln"]
+                    qkv = ops.gemm_nt(xb[0], w_g, bias=bias_b, ln_in=(lnp, colsum, eps)).view(B, Tn, 3 * D)
+                else:
+                    h = ops.layernorm_fwd(xs, *lw["ln1"], out_dtype=dtype)
+                    qkv = ops.gemm_nt(h, lw["wqkv"], bias=lw["bqkv"]).view(B, Tn, 3 * D)
+                o = ops.attn_fwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H, scale=1.0, use_mfma=use_mfma,
+                                 workspace=self._attn_ws if self.attn_split else None)
+                ops.gemm_nt(o.view(B * Tn, D), lw["wo"], bias=lw["bo"], no_out=True, planes_out=planes, ln_out=(lnp, None),
+                            **(dict(planes_res=planes) if have else dict(residual=xs)))
+                w_g, colsum, bias_b = lw["fc1_ln"]
+                f = ops.gemm_nt(xb[0], w_g, bias=bias_b, act=ops.ACT_GELU, ln_in=(lnp, colsum, eps))
+                # the stream stays in the planes if its next reader is the next layer's folded QKV product; else
+                # (last layer, or a last layer that runs on the kept rows only) it goes back to fp32
+                have = li < last and not (n_keep < Tn and li + 1 == last)
+                if have:
+                    ops.gemm_nt(f, lw["wfc2"], bias=lw["bfc2"], no_out=True, planes_res=planes, planes_out=planes,
+                                ln_out=(lnp, None))
+                else:
+                    ops.gemm_nt(f, lw["wfc2"], bias=lw["bfc2"], planes_res=planes, out=xs)
+                continue
             h = ops.layernorm_fwd(xs, *lw["ln1"], out_dtype=dtype)
-            if n_keep < Tn and li == len(pk["layers"]) - 1:
+            if pruned:
                 kv = ops.gemm_nt(h, lw["wqkv"][D:], bias=lw["bqkv"][D:]).view(B, Tn, 2 * D)
                 q = ops.gemm_nt(h.view(B, Tn, D)[:, :n_keep], lw["wqkv"][:D], bias=lw["bqkv"][:D])      # [B, n, D]
                 o = ops.attn_fwd(q, kv[:, :, :D], kv[:, :, D:], H, scale=1.0, use_mfma=use_mfma,

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 import oracle  # noqa: E402  (the checker)
 from mocov2_whisper_flamingo_amd import ops  # noqa: E402
 from tests.philox_ref import attn_keep_mask, keep_mask  # noqa: E402
+from tests.helpers import assert_close  # noqa: E402
 
 
 def rel_err(got, ref):
@@ -538,6 +539,63 @@ def test_stem_mfma(dev, H, W, train):
     y2 = ops.stem3d_fwd(video.to(dev), wp, torch.bfloat16, **({} if train else dict(scale=sc, shift=sh)),
                         **(dict(col_stats=(ops.stem_stats_slabs(video.to(dev))[0], ops.stem_stats_slabs(video.to(dev))[1])) if train else {}))
     assert rel_err(y, y2) < 2e-2
+
+
+@pytest.mark.parametrize("M,D,N2", [(300, 384, 1152), (12000, 768, 2304), (1500, 768, 3072), (777, 1280, 640)])
+@pytest.mark.parametrize("act", ["none", "gelu"])
+def test_layernorm_folded_into_the_products_around_it(dev, M, D, N2, act):
+    """x = residual + o @ Wo^T + bo (fp32), y = act(LayerNorm(x) @ W^T + b): the first product leaves a bf16 copy of x and
+    per-tile row sums, the second one normalises in its epilogue - against the same chain in fp32 on the CPU, at the
+    bf16 tolerance, and against the unfolded device path (LayerNorm kernel between the two products)."""
+    g = torch.Generator().manual_seed(M + D)
+    o = rnd(g, M, D, dtype=torch.bfloat16)
+    wo = (torch.randn(D, D, generator=g) * D ** -0.5).to(torch.bfloat16)
+    bo = torch.randn(D, generator=g) * 0.1
+    # rows with a mean well away from zero and a few large channels, as a transformer's residual stream has
+    res = torch.randn(M, D, generator=g) + torch.randn(M, 1, generator=g) * 0.5
+    res[:, 7] += 20.0
+    gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.2
+    w = torch.randn(N2, D, generator=g) * D ** -0.5
+    b = torch.randn(N2, generator=g) * 0.1
+    x_ref = res + o.float() @ wo.float().t() + bo
+    y_ref = F.layer_norm(x_ref, (D,), gamma, beta) @ w.t() + b
+    if act == "gelu":
+        y_ref = F.gelu(y_ref)
+    # folded
+    xs = res.to(dev).clone()
+    parts = torch.full((ops.row_lse_parts(D), M, 2), float("nan"), device=dev)
+    xb = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
+    ops.gemm_nt(o.to(dev).to(torch.bfloat16), wo.to(dev), bias=bo.to(dev), residual=xs, out=xs, ln_out=(parts, xb))
+    assert rel_err(xs, x_ref) < 1e-2 and torch.equal(xb, xs.to(torch.bfloat16))
+    assert torch.allclose(parts[:, :, 0].sum(0).cpu(), x_ref.sum(1), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(parts[:, :, 1].sum(0).cpu(), (x_ref * x_ref).sum(1), rtol=1e-3, atol=1e-2)
+    w_g, colsum, bias_b = ops.ln_fold_weights(w.to(dev), b.to(dev), gamma.to(dev), beta.to(dev))
+    y = ops.gemm_nt(xb, w_g, bias=bias_b, act=ops.ACT_GELU if act == "gelu" else ops.ACT_NONE, ln_in=(parts, colsum, 1e-5))
+    assert y.dtype == torch.bfloat16 and y.shape == (M, N2)
+    assert_close(y, y_ref, 2e-2, f"LN-folded product {M}x{D}x{N2} {act}")
+    # the stored rows as two bf16 planes (hi + lo = the fp32 value to 2^-18), updated in place by a second product
+    pl = torch.empty(2, M, D, dtype=torch.bfloat16, device=dev)
+    parts2 = torch.full_like(parts, float("nan"))
+    ops.gemm_nt(o.to(dev).to(torch.bfloat16), wo.to(dev), bias=bo.to(dev), residual=res.to(dev), no_out=True,
+                planes_out=(pl[0], pl[1]), ln_out=(parts2, None))
+    assert torch.equal(pl[0], xb) and torch.equal(parts2, parts)
+    assert ((pl[0].float() + pl[1].float()) - xs).abs().max() <= 2.0 ** -16 * xs.abs().max()
+    o2 = rnd(g, M, D, dtype=torch.bfloat16).to(dev).to(torch.bfloat16)
+    x2_ref = x_ref + o2.float().cpu() @ wo.float().t() + bo
+    ops.gemm_nt(o2, wo.to(dev), bias=bo.to(dev), no_out=True, planes_res=(pl[0], pl[1]), planes_out=(pl[0], pl[1]),
+                ln_out=(parts2, None))
+    assert rel_err(pl[0].float() + pl[1].float(), x2_ref) < 1e-2
+    assert torch.allclose(parts2[:, :, 0].sum(0).cpu(), x2_ref.sum(1), rtol=1e-3, atol=2e-2)
+    back = torch.empty(M, D, device=dev)
+    ops.gemm_nt(o2, wo.to(dev), bias=bo.to(dev), planes_res=(pl[0], pl[1]), out=back)     # planes -> fp32, no statistics
+    assert rel_err(back, x2_ref + o2.float().cpu() @ wo.float().t() + bo) < 1e-2
+    # the unfolded path on the same stored rows
+    h = ops.layernorm_fwd(xs, gamma.to(dev), beta.to(dev), out_dtype=torch.bfloat16)
+    y2 = ops.gemm_nt(h, w.to(dev).to(torch.bfloat16), bias=b.to(dev), act=ops.ACT_GELU if act == "gelu" else ops.ACT_NONE)
+    e_fold = (y.float().cpu() - y_ref).norm() / y_ref.norm()
+    e_plain = (y2.float().cpu() - y_ref).norm() / y_ref.norm()
+    print(f"LN fold {M}x{D}x{N2} {act}: l2 folded {e_fold:.2e}  unfolded {e_plain:.2e}")
+    assert e_fold < 2.0 * e_plain + 1e-3
 
 
 def test_stem_reads_its_input_through_a_device_word(dev):
