@@ -352,6 +352,15 @@ int avsr_maxpool3x3s2(avsr_stream_t stream, int in_dtype, int out_dtype, const v
 /* The two steps before it in training mode as one launch: the last Bottleneck's bn3 apply + shortcut + ReLU (torchvision
  * Bottleneck.forward, instantiated at moco_visual_frontend.py:27-31) and the pool + mask (:41-51) - the normalised
  * activation nobody else reads is never written.  x, residual: bf16 [B*T, HW, C]; y [B*T, C] bf16 or fp32. */
+/* avsr_bn_finalize followed by avsr_bn_apply (bf16 in and out, residual without an affine of its own) as ONE launch, for
+ * statistics slabs of at most 256 rows and C a multiple of 64 (the deep, small feature maps of the trunk, where the
+ * separate finalize launch costs as much as the apply pass): every workgroup folds the slab rows of its 64 channels
+ * itself.  scale_out / shift_out (optional) receive the affine; the running statistics are updated once.
+ * torch nn.BatchNorm2d in training mode, as avsr_bn_finalize (moco_visual_frontend.py:27-31 via torchvision). */
+int avsr_bn_finalize_apply(avsr_stream_t stream, const void* x, const void* residual, void* y, const float* sum,
+                           const float* sumsq, int64_t nparts, double count, const float* weight, const float* bias,
+                           float* running_mean, float* running_var, float* scale_out, float* shift_out, int64_t rows,
+                           int64_t C, float eps, float momentum, int relu);
 int avsr_bn_apply_avgpool_mask(avsr_stream_t stream, int out_dtype, const void* x, const void* residual,
                                const float* scale, const float* shift, void* y, const int64_t* lens, int64_t B,
                                int64_t T, int64_t HW, int64_t C);

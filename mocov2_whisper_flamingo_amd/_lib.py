@@ -95,6 +95,8 @@ SIGNATURES = {
     "avsr_maxpool3x3s2": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
     "avsr_avgpool_mask_fwd": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
     "avsr_bn_apply_avgpool_mask": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
+    "avsr_bn_finalize_apply": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
+                                      _f32, _f32, _i32]),
     "avsr_bn_finalize": (_i32, [_vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp]),
     "avsr_bn_finalize_workspace_floats": (_i64, [_i64]),
     "avsr_gemm_stats_parts": (_i64, [_i32, _i64]),

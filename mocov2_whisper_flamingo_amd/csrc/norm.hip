@@ -384,20 +384,21 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
 }
 
 // Both steps in one launch for up to a few thousand slab rows.  grid = (ceil(C/64), S): workgroup (g, s) sums
-// slice s of the slab rows for channels 64g..64g+63 - its 16 waves take interleaved rows (16 loads in flight per
+// slice s of the slab rows for channels 64g..64g+63 - its NW waves take interleaved rows (16 loads in flight per
 // lane) and fold through LDS in a fixed order.  S = 1: it finalises directly.  S > 1 (thousands of rows: one
 // workgroup per 64 channels would read megabytes alone): it publishes its partial sums in `ws`, takes a ticket,
 // and the workgroup that draws the last ticket adds the S partials in slice order (so the result does not depend
 // on which workgroup that is), finalises and puts the ticket counter back to zero.
 #define BN_FUSED_MAX_PARTS 8192
 #define BN_SPLIT_MAX 16
-__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void bn_reduce_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq,
                                                                   int nparts, float count, const float* __restrict__ weight,
                                                                   const float* __restrict__ bias, float* __restrict__ running_mean,
                                                                   float* __restrict__ running_var, float* __restrict__ scale,
                                                                   float* __restrict__ shift, int C, float eps, float momentum,
                                                                   float* __restrict__ ws, int* __restrict__ tickets) {
-    __shared__ float red[2][16][64];
+    __shared__ float red[2][NW][64];
     __shared__ int last;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -411,21 +412,21 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
 #pragma unroll
     for (int u = 0; u < 8; ++u) { a[u] = 0.f; b[u] = 0.f; }
     int p = slice * per + w;
-    for (; p + 16 * 7 < p_end; p += 16 * 8) {
+    for (; p + NW * 7 < p_end; p += NW * 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            a[u] += sum[(long)(p + 16 * u) * C + cc];
-            b[u] += sumsq[(long)(p + 16 * u) * C + cc];
+            a[u] += sum[(long)(p + NW * u) * C + cc];
+            b[u] += sumsq[(long)(p + NW * u) * C + cc];
         }
     }
-    for (; p < p_end; p += 16) { a[0] += sum[(long)p * C + cc]; b[0] += sumsq[(long)p * C + cc]; }
+    for (; p < p_end; p += NW) { a[0] += sum[(long)p * C + cc]; b[0] += sumsq[(long)p * C + cc]; }
     red[0][w][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     red[1][w][lane] = ((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]));
     __syncthreads();
     float s = 0.f, q = 0.f;
     if (w == 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s += red[0][i][lane]; q += red[1][i][lane]; }
+        for (int i = 0; i < NW; ++i) { s += red[0][i][lane]; q += red[1][i][lane]; }
     }
     if (S > 1) {
         if (w == 0 && c < C) {
@@ -548,6 +549,119 @@ __global__ __launch_bounds__(256) void bn_apply_bf16x8_kernel(const bf16_t* x, c
         *(bf16x8*)(y + i * 8) = o0;
         if (two) *(bf16x8*)(y + j * 8) = o1;
     }
+}
+
+// Training-mode BatchNorm of a convolution output with FEW slab rows (the deep, small feature maps: a few hundred row
+// tiles), finalize and apply in one launch: workgroup (g, chunk) folds the slab rows of channels 64g .. 64g + 63 itself
+// (its waves take interleaved rows; every workgroup of a channel group adds the same numbers in the same order, so they
+// all hold the same affine) and then normalises its chunk of rows of that 64-channel slice - 128 contiguous bytes per
+// row.  Chunk 0 of each channel group also updates the running statistics and publishes scale / shift.  A launch
+// (and the dependent-launch gap before it) less per BatchNorm; the slabs are read once per workgroup, which is why
+// this form is for short slabs only.
+#define BFA_MAX_PARTS 256
+#ifndef BFA_TARGET_WGS
+#define BFA_TARGET_WGS 256
+#endif
+// Waves per workgroup: 16 is fastest when the visual frontend runs alone (3.63 -> 3.56 ms per pass), but beside the audio
+// encoder's GEMMs a 1024-thread workgroup waits for a CU with sixteen free wave slots: in the whole step 16 waves lose
+// 0.02 ms against the two separate launches, 8 (or 4) waves gain 0.08 ms.
+#define BFA_WAVES 8
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void bn_finalize_apply_kernel(const bf16_t* x, const bf16_t* res, bf16_t* y,   // y may be x
+                                                                 const float* __restrict__ sum, const float* __restrict__ sumsq,
+                                                                 int nparts, float count, const float* __restrict__ weight,
+                                                                 const float* __restrict__ bias, float* __restrict__ running_mean,
+                                                                 float* __restrict__ running_var, float* __restrict__ scale_out,
+                                                                 float* __restrict__ shift_out, long rows, int C, float eps,
+                                                                 float momentum, int relu, long rows_per_chunk) {
+    __shared__ float red[2][NW][64];
+    constexpr int RPI = 8 * NW;                                 // rows per pass of the workgroup (8 threads per row)
+    __shared__ float aff[2][64];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float pw = 0.f, pb = 0.f, prm = 0.f, prv = 0.f;
+    const bool first = blockIdx.y == 0;
+    if (w == 0) { pw = weight[c]; pb = bias[c]; if (first && running_mean) { prm = running_mean[c]; prv = running_var[c]; } }
+    // the first rows of the chunk do not depend on the statistics: request them ahead of the reduction
+    const int q8 = t & 7, r = t >> 3;
+    const long r_begin = (long)blockIdx.y * rows_per_chunk, r_end = min(rows, r_begin + rows_per_chunk);
+    const long col = (long)blockIdx.x * 64 + q8 * 8;
+    long row = r_begin + r;
+    bf16x8 a0 = {}, a1 = {}, r0 = {}, r1 = {};
+    if (row < r_end) { a0 = *(const bf16x8*)(x + row * C + col); if (res) r0 = *(const bf16x8*)(res + row * C + col); }
+    if (row + RPI < r_end) { a1 = *(const bf16x8*)(x + (row + RPI) * C + col); if (res) r1 = *(const bf16x8*)(res + (row + RPI) * C + col); }
+    float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    int p = w;
+    for (; p + NW * 3 < nparts; p += NW * 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sa[u] += sum[(long)(p + NW * u) * C + c]; sb[u] += sumsq[(long)(p + NW * u) * C + c]; }
+    }
+    for (; p < nparts; p += NW) { sa[0] += sum[(long)p * C + c]; sb[0] += sumsq[(long)p * C + c]; }
+    red[0][w][lane] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    red[1][w][lane] = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+    __syncthreads();
+    if (w == 0) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { s += red[0][i][lane]; q += red[1][i][lane]; }
+        const float mean = s / count;
+        const float var = fmaxf(q / count - mean * mean, 0.f);
+        const float sc = pw * rsqrtf(var + eps), sh = pb - mean * sc;
+        aff[0][lane] = sc; aff[1][lane] = sh;
+        if (first) {
+            if (scale_out) { scale_out[c] = sc; shift_out[c] = sh; }
+            if (running_mean) {
+                const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+                running_mean[c] = (1.f - momentum) * prm + momentum * mean;
+                running_var[c] = (1.f - momentum) * prv + momentum * unb;
+            }
+        }
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = aff[0][q8 * 8 + e]; sh[e] = aff[1][q8 * 8 + e]; }
+    for (; row < r_end; row += 2 * RPI) {
+        const bool two = row + RPI < r_end;
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v0 = fmaf((float)a0[e], sc[e], sh[e]), v1 = fmaf((float)a1[e], sc[e], sh[e]);
+            if (res) { v0 += (float)r0[e]; v1 += (float)r1[e]; }
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            o0[e] = (bf16_t)v0; o1[e] = (bf16_t)v1;
+        }
+        // the next pair of rows is requested before this pair is stored
+        const long nrow = row + 2 * RPI;
+        bf16x8 n0 = {}, n1 = {}, m0 = {}, m1 = {};
+        if (nrow < r_end) { n0 = *(const bf16x8*)(x + nrow * C + col); if (res) m0 = *(const bf16x8*)(res + nrow * C + col); }
+        if (nrow + RPI < r_end) { n1 = *(const bf16x8*)(x + (nrow + RPI) * C + col); if (res) m1 = *(const bf16x8*)(res + (nrow + RPI) * C + col); }
+        *(bf16x8*)(y + row * C + col) = o0;
+        if (two) *(bf16x8*)(y + (row + RPI) * C + col) = o1;
+        a0 = n0; a1 = n1; r0 = m0; r1 = m1;
+    }
+}
+
+extern "C" int avsr_bn_finalize_apply(avsr_stream_t stream, const void* x, const void* residual, void* y, const float* sum,
+                                      const float* sumsq, int64_t nparts, double count, const float* weight,
+                                      const float* bias, float* running_mean, float* running_var, float* scale_out,
+                                      float* shift_out, int64_t rows, int64_t C, float eps, float momentum, int relu) {
+    if (!x || !y || !sum || !sumsq || !weight || !bias || rows <= 0 || C <= 0 || nparts <= 0 || count <= 0) return AVSR_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr) || (scale_out == nullptr) != (shift_out == nullptr)) return AVSR_EINVAL;
+    if (C % 64 || nparts > BFA_MAX_PARTS || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) % 16)) return AVSR_EUNSUPPORTED;
+    const long groups = C / 64;
+    long chunks = std::max<long>(1, BFA_TARGET_WGS / groups);
+    chunks = std::min<long>(chunks, (rows + 255) / 256);
+    const long rows_per_chunk = (rows + chunks - 1) / chunks;
+    chunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+    if (chunks > 65535) return AVSR_EUNSUPPORTED;
+#define L(NWV) hipLaunchKernelGGL(bn_finalize_apply_kernel<NWV>, dim3((unsigned)groups, (unsigned)chunks), dim3(64 * NWV), 0, \
+                       (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, sum, sumsq, (int)nparts, \
+                       (float)count, weight, bias, running_mean, running_var, scale_out, shift_out, (long)rows, (int)C, eps, \
+                       momentum, relu, rows_per_chunk)
+    L(BFA_WAVES);
+#undef L
+    return avsr_launch_status();
 }
 
 // ---- batch statistics of a 1x1 convolution's OUTPUT from the second moments of its INPUT -----------------------
@@ -690,9 +804,13 @@ extern "C" int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const fl
         // thousands of rows: split them over up to 16 workgroups per 64 channels when the caller lends the buffers
         int S = 1;
         if (ws && tickets && nparts >= 512) S = (int)std::min<int64_t>(BN_SPLIT_MAX, nparts / 256);
-        hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)S), dim3(1024), 0, s, sum, sumsq,
-                           (int)nparts, (float)count, weight, bias, running_mean, running_var, scale, shift, (int)C, eps,
-                           momentum, ws, tickets);
+        // 8 waves per workgroup: sixteen fold a slab a little faster alone, but a 1024-thread workgroup waits for a CU
+        // with sixteen free wave slots while the other streams' GEMMs hold the chip (0.04 ms of the step)
+#define L(NWV) hipLaunchKernelGGL(bn_reduce_finalize_kernel<NWV>, dim3((unsigned)((C + 63) / 64), (unsigned)S), dim3(64 * NWV), 0, s, sum, sumsq, \
+                           (int)nparts, (float)count, weight, bias, running_mean, running_var, scale, shift, (int)C, eps, \
+                           momentum, ws, tickets)
+        L(8);
+#undef L
     } else if (nparts > BN_RED_PARTS) {
         if (!ws) return AVSR_EINVAL;
         hipLaunchKernelGGL(bn_reduce_parts_kernel, dim3((unsigned)((C + 63) / 64), BN_RED_PARTS), dim3(256), 0, s, sum, sumsq,

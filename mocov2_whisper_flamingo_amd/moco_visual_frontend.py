@@ -78,6 +78,7 @@ class MoCoVisualFrontend(nn.Module):
         self.gram_bn3 = os.environ.get("AVSR_GRAM_BN3", "1") != "0"
         self.gram_widths = (64,) if os.environ.get("AVSR_GRAM_BN3") == "64" else (64, 128)
         self.gram_downsample = os.environ.get("AVSR_GRAM_DS", "1") != "0"      # layer1.0's shortcut BN the same way
+        self.fuse_finalize = os.environ.get("AVSR_BN_FUSE_FINALIZE", "1") != "0"
         self._packed = None
         self._stats_epoch = 0                   # bumped by every batch-statistics forward (the kernels write the buffers raw)
         self._tracked_pending = 0               # training-mode forwards not yet added to num_batches_tracked
@@ -164,6 +165,12 @@ class MoCoVisualFrontend(nn.Module):
             out = ops.conv_nhwc(x, w, 1, 1, 1, 0, scale=aff[0], bias=aff[1], act=act, residual=res2d)
             return (out, None) if defer else out
         raw = ops.conv_nhwc(x, w, k, k, stride, pad, col_stats=(stats[0], stats[1]))
+        if (self.fuse_finalize and not defer and residual_affine is None and raw.dtype == torch.bfloat16 and C % 64 == 0
+                and stats.shape[1] <= ops.BN_FUSED_APPLY_MAX_PARTS):
+            # short slabs (the deep, small feature maps): the apply pass folds them itself, one launch instead of two
+            return ops.bn_finalize_apply(raw, stats[0], stats[1], rows, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                         bn.running_var, residual=residual, relu=relu, out=raw, eps=bn.eps,
+                                         momentum=bn.momentum)
         ops.bn_finalize(stats[0], stats[1], rows, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                         bn.running_var, aff[0], aff[1], bn.eps, bn.momentum)
         if defer:

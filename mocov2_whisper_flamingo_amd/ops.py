@@ -554,6 +554,29 @@ def bn_finalize(col_sum, col_sumsq, count, weight, bias, running_mean, running_v
                                C, eps, momentum, _p(ws), _p(tickets)), "avsr_bn_finalize")
 
 
+BN_FUSED_APPLY_MAX_PARTS = 256
+
+
+def bn_finalize_apply(x, col_sum, col_sumsq, count, weight, bias, running_mean, running_var, *, residual=None, relu=True,
+                      out=None, affine_out=None, eps=1e-5, momentum=0.1):
+    """bn_finalize + bn_apply in one launch: bf16 x [..., C] (C a multiple of 64), slabs of at most
+    BN_FUSED_APPLY_MAX_PARTS rows.  ``affine_out`` = (scale, shift) also receives the affine."""
+    lib = _lib.load()
+    C = weight.numel()
+    nparts = col_sum.numel() // C
+    y = out if out is not None else torch.empty_like(x)
+    _need_cuda(x, col_sum, col_sumsq, weight, bias, residual, y)
+    if x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16 or not x.is_contiguous() or not y.is_contiguous() or (
+            residual is not None and (residual.dtype != torch.bfloat16 or not residual.is_contiguous())):
+        raise ValueError("bn_finalize_apply takes contiguous bf16 tensors")
+    sc, sh = affine_out if affine_out is not None else (None, None)
+    check(lib.avsr_bn_finalize_apply(_stream(), x.data_ptr(), _p(residual), y.data_ptr(), col_sum.data_ptr(),
+                                     col_sumsq.data_ptr(), nparts, float(count), weight.data_ptr(), bias.data_ptr(),
+                                     _p(running_mean), _p(running_var), _p(sc), _p(sh), x.numel() // C, C, eps, momentum,
+                                     int(relu)), "avsr_bn_finalize_apply")
+    return y
+
+
 def gram_stats(x):
     """Per-share partial Gram matrices and column sums of x [M, K] bf16 (K = 64 or 128, unit inner stride):
     (gram_parts fp32 [parts, K, K], colsum_parts fp32 [parts, K]) for bn_gram_finalize."""

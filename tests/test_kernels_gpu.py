@@ -650,6 +650,41 @@ def test_bn_finalize_slabs(dev, nparts, C):
     assert all(int(t.abs().sum()) == 0 for t in ops._BN_TICKETS.values())
 
 
+@pytest.mark.parametrize("rows,C,nparts,res", [(29400, 256, 230, False), (29400, 1024, 230, True), (9600, 512, 75, False),
+                                               (9600, 2048, 75, True), (300, 64, 3, True), (1000, 128, 256, False)])
+def test_bn_finalize_and_apply_in_one_launch(dev, rows, C, nparts, res):
+    """avsr_bn_finalize_apply against the two launches it replaces: same output (bf16 ulp: the slab rows are added in
+    another order), same affine and running statistics; against the definition on the CPU as well."""
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.3).to(torch.bfloat16).to(dev)
+    r = torch.randn(rows, C, generator=g).to(torch.bfloat16).to(dev) if res else None
+    xf = x.float().cpu()
+    # slabs as a producer would leave them: row p holds the sums of rows p, p + nparts, ...
+    per = (rows + nparts - 1) // nparts
+    pad = torch.zeros(per * nparts, C)
+    pad[:rows] = xf
+    cs, cq = pad.view(nparts, per, C).sum(1).to(dev), (pad * pad).view(nparts, per, C).sum(1).to(dev)
+    w, b = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.2).to(dev)
+    rm, rv = torch.randn(C, generator=g).to(dev), (torch.rand(C, generator=g) + 0.5).to(dev)
+    rm2, rv2 = rm.clone(), rv.clone()
+    sc, sh = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    ops.bn_finalize(cs, cq, rows, w, b, rm, rv, sc, sh)
+    want = ops.bn_apply(x, sc, sh, residual=r, relu=True)
+    sc2, sh2 = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    got = ops.bn_finalize_apply(x, cs, cq, rows, w, b, rm2, rv2, residual=r, relu=True, affine_out=(sc2, sh2))
+    assert torch.allclose(sc2, sc, rtol=1e-5, atol=1e-6) and torch.allclose(sh2, sh, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(rm2, rm, rtol=1e-5, atol=1e-6) and torch.allclose(rv2, rv, rtol=1e-5, atol=1e-6)
+    d = (got.float() - want.float()).abs()
+    assert (d <= 2.0 ** -7 * want.float().abs() + 1e-6).all() and (d > 0).float().mean() < 1e-2
+    ref = F.relu(F.batch_norm(xf.t().unsqueeze(0), None, None, w.cpu(), b.cpu(), True).squeeze(0).t()
+                 + (r.float().cpu() if res else 0))
+    assert rel_err(got, ref) < 2e-2
+    # in place, and without the optional outputs
+    x2 = x.clone()
+    assert ops.bn_finalize_apply(x2, cs, cq, rows, w, b, None, None, residual=r, relu=True, out=x2) is x2
+    assert torch.equal(x2, got)
+
+
 @pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("hw,C", [((4, 4), 2048), ((3, 3), 64), ((1, 5), 4096)])
 def test_bn_apply_folded_into_the_average_pool(dev, odt, hw, C):
