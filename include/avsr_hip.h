@@ -408,6 +408,11 @@ int avsr_bn_finalize(avsr_stream_t stream, const float* sum, const float* sumsq,
 int64_t avsr_gram_parts(int64_t M, int64_t K);
 int avsr_gram_stats(avsr_stream_t stream, const void* X, int64_t ldx, int64_t M, int64_t K, float* gram_parts,
                     float* colsum_parts);
+/* avsr_gram_stats of relu(X * scale + shift) - X being the RAW output of the convolution before (conv2 of the
+ * Bottleneck, its bn2 affine in scale / shift) - which also stores that normalised tensor to Y (row pitch ldy; Y may
+ * be X): bn2's apply pass rides in the statistics pass that reads the tensor anyway. */
+int avsr_gram_stats_bn(avsr_stream_t stream, const void* X, int64_t ldx, int64_t M, int64_t K, const float* scale,
+                       const float* shift, void* Y, int64_t ldy, float* gram_parts, float* colsum_parts);
 int64_t avsr_bn_gram_workspace_doubles(int64_t K);
 int avsr_bn_gram_finalize(avsr_stream_t stream, const float* gram_parts, const float* colsum_parts, int64_t parts,
                           int64_t K, double count, const void* W_bf16, int64_t ldw, int64_t N, const float* weight,

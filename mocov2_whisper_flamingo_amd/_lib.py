@@ -103,6 +103,7 @@ SIGNATURES = {
     "avsr_stem3d_stats_parts": (_i64, [_i64, _i64, _i64, _i64]),
     "avsr_gram_parts": (_i64, [_i64, _i64]),
     "avsr_gram_stats": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "avsr_gram_stats_bn": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),
     "avsr_bn_gram_workspace_doubles": (_i64, [_i64]),
     "avsr_bn_gram_finalize": (_i32, [_vp, _vp, _vp, _i64, _i64, _f64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _f32, _f32, _vp]),

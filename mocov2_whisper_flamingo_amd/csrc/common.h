@@ -235,6 +235,14 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // per-lane pointer and pays a 64-bit vector add per piece and K-step).  M0 carries the LDS destination and is
 // compiler-reserved: saved and restored inside the statement.  The compiler does not count this load: every
 // user waits with an explicit s_waitcnt vmcnt before the barrier that publishes the stage.
+// The per-lane-address form of the same load, also hidden from the compiler (which waits for vmcnt(0) before the next
+// LDS read wherever it has seen the builtin on some path to it).
+__device__ __forceinline__ void dma_lane(uintptr_t gaddr, const char* lds_dst) {
+    unsigned keep;
+    const unsigned ldsa = (unsigned)(uintptr_t)(lptr_t)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gaddr), "s"(ldsa) : "memory");
+}
 __device__ __forceinline__ void dma_piece(const char* sbase, unsigned voff, const char* lds_dst) {
     unsigned keep;
     const unsigned ldsa = (unsigned)(uintptr_t)(lptr_t)lds_dst;

@@ -50,11 +50,19 @@ template <int TB, int NST, bool GRAM = false> constexpr int tn_lds_bytes() { ret
 // read from it).  The rows are cut into gridDim.x shares, one workgroup each, on every XCD; share p stores its partial
 // product at C + p * part_stride and its column sums at colsum + p * N with plain stores (no atomics: the caller adds
 // the shares in a fixed order).
-template <int TB, int NST, bool GRAM = false>
-__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
+// APPLY (with GRAM): the operand in memory is a RAW convolution output whose batch-norm affine + ReLU has not been
+// applied yet: every lane normalises the chunks it DMA'd, in LDS, before the stage is published, and stores them to Y
+// (which may be A itself) - the Gram statistics are those of the normalised tensor, and the separate apply pass over it
+// (a read and a launch) is gone.  Rows past M stay zero.
+template <int TB, int NST, bool GRAM = false, bool APPLY = false>
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* A, long lda, const bf16_t* B,
                                                            long ldb, float* __restrict__ C, long ldc, int M, int N, int K,
                                                            int accumulate, float* __restrict__ colsum, int accumulate_colsum,
-                                                           int ntiles, int ktiles, int nsplit, long part_stride) {
+                                                           int ntiles, int ktiles, int nsplit, long part_stride,
+                                                           const float* __restrict__ ascale = nullptr,
+                                                           const float* __restrict__ ashift = nullptr, bf16_t* Y = nullptr,
+                                                           long ldy = 0) {
+    static_assert(!APPLY || GRAM, "the in-flight normalisation exists for the Gram form only");
     constexpr int TILE = 64 * TB, SUB = 64 * 64;              // an operand stage is TB sub-tiles of [64 rows][64 cols]
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     bf16_t* As = (bf16_t*)lds_raw;                            // [NST][TB][SUB]
@@ -114,7 +122,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
                 const bool oka = m < M && ca < N && ca + 8 <= lda, okb = m < M && cb < K && cb + 8 <= ldb;
                 const uintptr_t pa = zaddr + ((ra - zaddr) & (uintptr_t)(-(long)oka));
                 const uintptr_t pb = zaddr + ((rb - zaddr) & (uintptr_t)(-(long)okb));
-                __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)&As[(buf * TB + sub) * SUB + (2 * wave + i) * 512], 16, 0, 0);
+                if constexpr (APPLY) dma_lane(pa, (const char*)&As[(buf * TB + sub) * SUB + (2 * wave + i) * 512]);
+                else __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)&As[(buf * TB + sub) * SUB + (2 * wave + i) * 512], 16, 0, 0);
                 if constexpr (!GRAM)
                     __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)&Bs[(buf * TB + sub) * SUB + (2 * wave + i) * 512], 16, 0, 0);
             }
@@ -145,9 +154,43 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
     const int allsteps = (M + 63) >> 6;
     const int st0 = (int)((long)part * allsteps / nsplit), nsteps = (int)((long)(part + 1) * allsteps / nsplit) - st0;
     const int mbase = 64 * st0;
+    // APPLY: the affine of this lane's eight channels per sub-tile (the swizzled chunk it moves is the same in both of
+    // its pieces), and the pass over the stage that has just landed
+    float asc[APPLY ? TB : 1][8], ash[APPLY ? TB : 1][8];
+    const int ach = pch ^ (((prow >> 1) & 1) << 2);
+    if constexpr (APPLY) {
+#pragma unroll
+        for (int sub = 0; sub < TB; ++sub)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = min(64 * sub + ach * 8 + e, N - 1);
+                asc[sub][e] = ascale[c]; ash[sub][e] = ashift[c];
+            }
+    }
+    auto normalise = [&](int m0, int buf) {
+        if constexpr (APPLY) {
+#pragma unroll
+            for (int sub = 0; sub < TB; ++sub)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int rr = (2 * wave + i) * 8 + prow;
+                    const long m = m0 + rr;
+                    const int col = 64 * sub + ach * 8;
+                    bf16_t* lp = &As[(buf * TB + sub) * SUB + (2 * wave + i) * 512 + lane * 8];
+                    const bf16x8 v = *(const bf16x8*)lp;
+                    const bool ok = m < M && col < N;
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(ok ? fmaxf(fmaf((float)v[e], asc[sub][e], ash[sub][e]), 0.f) : 0.f);
+                    *(bf16x8*)lp = o;
+                    if (ok) *(bf16x8*)(Y + m * ldy + col) = o;
+                }
+        }
+    };
     dma_tiles(mbase, 0);
     if (NST > 2 && nsteps > 1) dma_tiles(mbase + 64, 1);
     wait_oldest(nsteps > 1);
+    normalise(mbase, 0);
     __syncthreads();
     for (int st = 0, cur = 0; st < nsteps; ++st, cur = (cur + 1 == NST ? 0 : cur + 1)) {
         const int ahead = st + NST - 1;                       // its buffer was last read one barrier ago
@@ -174,7 +217,11 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) cs[a] += (float)as[a * SUB + t_off(16 * wave + r, lane >> 3) + (lane & 7)];
         }
-        wait_oldest(st + NST - 1 < nsteps);                   // the next stage is in LDS (a younger one may be in flight)
+        // the next stage is in LDS (a younger one may be in flight).  APPLY: the normalised rows stored two stages ago
+        // are waited for as well - loads return in order, so "at most the youngest stage's loads outstanding" still
+        // means the stage before it has landed, whatever the stores do
+        wait_oldest(st + NST - 1 < nsteps);
+        if (st + 1 < nsteps) normalise(mbase + 64 * (st + 1), cur + 1 == NST ? 0 : cur + 1);
         __syncthreads();
     }
     // accumulator: lane = column (K index), register i <-> row (i & 3) + 8 (i >> 2) + 4 hf.  A wave passes its
@@ -246,14 +293,15 @@ int launch_tn(hipStream_t s, const void* A, int64_t lda, const void* B, int64_t 
     return avsr_launch_status();
 }
 
-template <int TB, int NST>
-int launch_gram(hipStream_t s, const void* X, int64_t ldx, int64_t M, int64_t K, int64_t parts, float* G, float* colsum) {
+template <int TB, int NST, bool APPLY = false>
+int launch_gram(hipStream_t s, const void* X, int64_t ldx, int64_t M, int64_t K, int64_t parts, float* G, float* colsum,
+                const float* ascale = nullptr, const float* ashift = nullptr, void* Y = nullptr, int64_t ldy = 0) {
     constexpr int lds = tn_lds_bytes<TB, NST, true>();
     static avsr_dev_flags attr_set;
-    if (lds > 48 * 1024 && !avsr_allow_lds((const void*)gemm_tn_bf16_kernel<TB, NST, true>, lds, attr_set)) return AVSR_EHIP;
-    hipLaunchKernelGGL((gemm_tn_bf16_kernel<TB, NST, true>), dim3((unsigned)parts), dim3(256), lds, s, (const bf16_t*)X, (long)ldx,
-                       (const bf16_t*)X, (long)ldx, G, (long)K, (int)M, (int)K, (int)K, 0, colsum, 0, 1, 1, (int)parts,
-                       (long)(K * K));
+    if (lds > 48 * 1024 && !avsr_allow_lds((const void*)gemm_tn_bf16_kernel<TB, NST, true, APPLY>, lds, attr_set)) return AVSR_EHIP;
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<TB, NST, true, APPLY>), dim3((unsigned)parts), dim3(256), lds, s, (const bf16_t*)X,
+                       (long)ldx, (const bf16_t*)X, (long)ldx, G, (long)K, (int)M, (int)K, (int)K, 0, colsum, 0, 1, 1,
+                       (int)parts, (long)(K * K), ascale, ashift, (bf16_t*)Y, (long)ldy);
     return avsr_launch_status();
 }
 
@@ -283,6 +331,17 @@ extern "C" int avsr_gram_stats(avsr_stream_t stream, const void* X, int64_t ldx,
     const int64_t parts = avsr_gram_parts(M, K);
     if (K == 64) return launch_gram<1, 3>((hipStream_t)stream, X, ldx, M, K, parts, gram_parts, colsum_parts);
     return launch_gram<2, 3>((hipStream_t)stream, X, ldx, M, K, parts, gram_parts, colsum_parts);
+}
+
+extern "C" int avsr_gram_stats_bn(avsr_stream_t stream, const void* X, int64_t ldx, int64_t M, int64_t K, const float* scale,
+                                  const float* shift, void* Y, int64_t ldy, float* gram_parts, float* colsum_parts) {
+    if (!X || !Y || !scale || !shift || !gram_parts || !colsum_parts || M <= 0) return AVSR_EINVAL;
+    if (K != 64 && K != 128) return AVSR_EUNSUPPORTED;
+    if (ldx < K || ldx % 8 || (uintptr_t)X % 16 || M > 0x7fffffff || 64 * ldx * 2 > 0x7fffffffLL) return AVSR_EUNSUPPORTED;
+    if (ldy < K || ldy % 8 || (uintptr_t)Y % 16) return AVSR_EUNSUPPORTED;
+    const int64_t parts = avsr_gram_parts(M, K);
+    if (K == 64) return launch_gram<1, 3, true>((hipStream_t)stream, X, ldx, M, K, parts, gram_parts, colsum_parts, scale, shift, Y, ldy);
+    return launch_gram<2, 3, true>((hipStream_t)stream, X, ldx, M, K, parts, gram_parts, colsum_parts, scale, shift, Y, ldy);
 }
 
 extern "C" int avsr_gemm_tn(avsr_stream_t stream, const void* A, int64_t lda, const void* B, int64_t ldb, float* C,

@@ -79,6 +79,7 @@ class MoCoVisualFrontend(nn.Module):
         self.gram_widths = (64,) if os.environ.get("AVSR_GRAM_BN3") == "64" else (64, 128)
         self.gram_downsample = os.environ.get("AVSR_GRAM_DS", "1") != "0"      # layer1.0's shortcut BN the same way
         self.fuse_finalize = os.environ.get("AVSR_BN_FUSE_FINALIZE", "1") != "0"
+        self.gram_applies_bn2 = os.environ.get("AVSR_GRAM_APPLIES_BN2", "1") != "0"
         self._packed = None
         self._stats_epoch = 0                   # bumped by every batch-statistics forward (the kernels write the buffers raw)
         self._tracked_pending = 0               # training-mode forwards not yet added to num_batches_tracked
@@ -234,10 +235,16 @@ class MoCoVisualFrontend(nn.Module):
             else:
                 idt = self._conv_bn(y, e["wd"], 1, e["stride"], 0, blk.downsample[1], relu=False)
         h = h1 if gram_ds else self._conv_bn(y, e["w1"], 1, 1, 0, blk.bn1, relu=True)
-        h = self._conv_bn(h, e["w2"], 3, e["stride"], 1, blk.bn2, relu=True)
         width = e["w3"].shape[1]
-        if (self.training and self.gram_bn3 and ("wd" not in e or gram_ds) and h.dtype == torch.bfloat16
-                and width in self.gram_widths):
+        gram3 = (self.training and self.gram_bn3 and ("wd" not in e or gram_ds) and h.dtype == torch.bfloat16
+                 and width in self.gram_widths)
+        aff2 = None
+        if gram3 and self.gram_applies_bn2:
+            # bn2's apply pass rides in the Gram statistics pass below, which reads conv2's output anyway
+            h, aff2 = self._conv_bn(h, e["w2"], 3, e["stride"], 1, blk.bn2, relu=True, defer=True)
+        else:
+            h = self._conv_bn(h, e["w2"], 3, e["stride"], 1, blk.bn2, relu=True)
+        if gram3:
             # Identity-shortcut blocks of layer1 / layer2 (64 / 128 channels into conv3, whose 256- / 512-channel output
             # is what the block's HBM traffic consists of): the batch statistics of conv3's output follow from the
             # 64 x 64 / 128 x 128 Gram matrix of its INPUT (one pass over a tensor a quarter of the output's size), so
@@ -246,7 +253,7 @@ class MoCoVisualFrontend(nn.Module):
             bn3 = blk.bn3
             C = e["w3"].shape[0]
             rows = h.numel() // width
-            gp, cp = ops.gram_stats(h.view(rows, width))
+            gp, cp = ops.gram_stats(h.view(rows, width), affine=aff2)
             aff = torch.empty((2, C), dtype=torch.float32, device=h.device)
             ops.bn_gram_finalize(gp, cp, rows, e["w3"], bn3.weight.detach(), bn3.bias.detach(), bn3.running_mean,
                                  bn3.running_var, aff[0], aff[1], bn3.eps, bn3.momentum)

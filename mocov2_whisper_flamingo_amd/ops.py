@@ -577,9 +577,11 @@ def bn_finalize_apply(x, col_sum, col_sumsq, count, weight, bias, running_mean, 
     return y
 
 
-def gram_stats(x):
+def gram_stats(x, affine=None):
     """Per-share partial Gram matrices and column sums of x [M, K] bf16 (K = 64 or 128, unit inner stride):
-    (gram_parts fp32 [parts, K, K], colsum_parts fp32 [parts, K]) for bn_gram_finalize."""
+    (gram_parts fp32 [parts, K, K], colsum_parts fp32 [parts, K]) for bn_gram_finalize.
+    ``affine`` = (scale, shift): x is a raw convolution output; the statistics are those of relu(x * scale + shift),
+    which replaces x in place."""
     lib = _lib.load()
     _need_cuda(x)
     M, K = x.shape
@@ -590,6 +592,11 @@ def gram_stats(x):
         raise _lib.AvsrHipError("gram_stats: K must be 64 or 128")
     gp = torch.empty((parts, K, K), dtype=torch.float32, device=x.device)
     cp = torch.empty((parts, K), dtype=torch.float32, device=x.device)
+    if affine is not None:
+        _need_cuda(*affine)
+        check(lib.avsr_gram_stats_bn(_stream(), x.data_ptr(), x.stride(0), M, K, affine[0].data_ptr(), affine[1].data_ptr(),
+                                     x.data_ptr(), x.stride(0), gp.data_ptr(), cp.data_ptr()), "avsr_gram_stats_bn")
+        return gp, cp
     check(lib.avsr_gram_stats(_stream(), x.data_ptr(), x.stride(0), M, K, gp.data_ptr(), cp.data_ptr()), "avsr_gram_stats")
     return gp, cp
 

@@ -1076,3 +1076,13 @@ def test_bn_statistics_from_the_input_gram_matrix(dev, M, K, N):
     gp2, cp2 = ops.gram_stats(hd)
     ops.bn_gram_finalize(gp2, cp2, M, wd, gamma.to(dev), beta.to(dev), None, None, aff2[0], aff2[1])
     assert torch.equal(aff, aff2)
+    # the same statistics from the RAW tensor one BatchNorm earlier: the pass normalises it in flight (and in place)
+    raw = (torch.randn(M, K, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+    sc, sh = (torch.rand(K, generator=g) + 0.5).to(dev), (torch.randn(K, generator=g) * 0.3).to(dev)
+    sc[3] = -sc[3]                                          # a negative gain is legal
+    want_h = ops.bn_apply(raw, sc, sh, relu=True)
+    gp_w, cp_w = ops.gram_stats(want_h)
+    x = raw.clone()
+    gp_g, cp_g = ops.gram_stats(x, affine=(sc, sh))
+    assert torch.equal(x, want_h)
+    assert torch.equal(gp_g, gp_w) and torch.equal(cp_g, cp_w)
