@@ -215,7 +215,9 @@ class WhisperEncoder(nn.Module):
         last = len(pk["layers"]) - 1
         for li, lw in enumerate(pk["layers"]):
             pruned = n_keep < Tn and li == last
-            if fold and not pruned:
+            # (the last layer is never folded: it runs on the kept rows only when the caller reads a prefix of the frames,
+            # and ``rows=n`` promises the bits of the full result)
+            if fold and li < last:
                 if have:
                     w_g, colsum, bias_b = lw["qkv_ln"]
                     qkv = ops.gemm_nt(xb[0], w_g, bias=bias_b, ln_in=(lnp, colsum, eps)).view(B, Tn, 3 * D)
@@ -228,9 +230,9 @@ class WhisperEncoder(nn.Module):
                             **(dict(planes_res=planes) if have else dict(residual=xs)))
                 w_g, colsum, bias_b = lw["fc1_ln"]
                 f = ops.gemm_nt(xb[0], w_g, bias=bias_b, act=ops.ACT_GELU, ln_in=(lnp, colsum, eps))
-                # the stream stays in the planes if its next reader is the next layer's folded QKV product; else
-                # (last layer, or a last layer that runs on the kept rows only) it goes back to fp32
-                have = li < last and not (n_keep < Tn and li + 1 == last)
+                # the stream stays in the planes if its next reader is the next layer's folded QKV product; before the
+                # last layer it goes back to fp32
+                have = li + 1 < last
                 if have:
                     ops.gemm_nt(f, lw["wfc2"], bias=lw["bfc2"], no_out=True, planes_res=planes, planes_out=planes,
                                 ln_out=(lnp, None))
