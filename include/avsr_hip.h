@@ -337,12 +337,14 @@ int avsr_stem3d_fwd(avsr_stream_t stream, int out_dtype, const float* video, con
  * counterpart in the reference: a launch recorded in a HIP graph then follows the caller's current batch -
  * models/av_net.py:240 hands a fresh videoBatch every step - without a copy into a fixed buffer).  bf16 MFMA form
  * only (weight_frags required, W % 4 == 0); the stored address must be 16-byte aligned and stay valid until the
- * launch has finished.  avsr_store_u64 writes such a word in stream order. */
+ * launch has finished.  avsr_store_u64 writes such a word in stream order (and, optionally, copies n_words more
+ * 8-byte words from copy_src to copy_dst in the same launch: the other small inputs of such a recording). */
 int avsr_stem3d_fwd_indirect(avsr_stream_t stream, int out_dtype, const float* const* video_slot,
                              const float* weight_packed, const void* weight_frags, void* out, const float* scale,
                              const float* shift, float* col_sum, float* col_sumsq, int64_t B, int64_t T, int64_t H,
                              int64_t W);
-int avsr_store_u64(avsr_stream_t stream, uint64_t* dst, uint64_t value);
+int avsr_store_u64(avsr_stream_t stream, uint64_t* dst, uint64_t value, uint64_t* copy_dst, const uint64_t* copy_src,
+                   int64_t n_words);
 int64_t avsr_stem3d_stats_parts(int64_t B, int64_t T, int64_t H, int64_t W);
 /* bf16 MFMA-fragment copy of the stem weight (avsr_stem3d_frag_elems() bf16 values) from weight_packed */
 int64_t avsr_stem3d_frag_elems(void);

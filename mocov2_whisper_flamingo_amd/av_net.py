@@ -294,11 +294,15 @@ class AVNet(nn.Module):
             vstream.wait_stream(main)
 
         def visual_inputs():
-            st_in[4].copy_(videoLen, non_blocking=True)
             if slot is None:
+                st_in[4].copy_(videoLen, non_blocking=True)
                 st_in[2].copy_(videoBatch, non_blocking=True)
-            else:
-                ops.store_u64(slot, video.data_ptr())
+            else:                                             # the video's address and the lengths in one small launch
+                if videoLen.dtype == torch.int64 and videoLen.is_contiguous() and st_in[4].is_contiguous():
+                    ops.store_u64(slot, video.data_ptr(), copy=(st_in[4], videoLen))
+                else:
+                    st_in[4].copy_(videoLen, non_blocking=True)
+                    ops.store_u64(slot, video.data_ptr())
                 video.record_stream(vstream)
 
         with torch.cuda.stream(stream):

@@ -512,14 +512,21 @@ struct StepRecord { unsigned long long seed_delta; float lr, bc1, bc2; unsigned 
 static_assert(sizeof(StepRecord) == 32, "the step record is 32 bytes");
 __global__ void step_params_kernel(StepRecord* rec, StepRecord v) { *rec = v; }
 
-__global__ void store_u64_kernel(unsigned long long* dst, unsigned long long v) { *dst = v; }
+__global__ void store_u64_kernel(unsigned long long* dst, unsigned long long v, unsigned long long* cdst,
+                                 const unsigned long long* csrc, int n) {
+    if (threadIdx.x == 0) *dst = v;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) cdst[i] = csrc[i];
+}
 
 // One 8-byte word written in stream order (the value travels in the launch packet): e.g. the address a recorded
-// launch reads its input from (avsr_stem3d_fwd_indirect).
-extern "C" int avsr_store_u64(avsr_stream_t stream, uint64_t* dst, uint64_t value) {
-    if (!dst || (uintptr_t)dst % 8) return AVSR_EINVAL;
-    hipLaunchKernelGGL(store_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)dst,
-                       (unsigned long long)value);
+// launch reads its input from (avsr_stem3d_fwd_indirect).  copy_dst / copy_src / n_words (optional): a few more words
+// copied device to device by the same launch (the other small inputs of that recording).
+extern "C" int avsr_store_u64(avsr_stream_t stream, uint64_t* dst, uint64_t value, uint64_t* copy_dst, const uint64_t* copy_src,
+                              int64_t n_words) {
+    if (!dst || (uintptr_t)dst % 8 || n_words < 0 || n_words > (1 << 20)) return AVSR_EINVAL;
+    if (n_words > 0 && (!copy_dst || !copy_src || ((uintptr_t)copy_dst | (uintptr_t)copy_src) % 8)) return AVSR_EINVAL;
+    hipLaunchKernelGGL(store_u64_kernel, dim3(1), dim3(n_words > 64 ? 256 : 64), 0, (hipStream_t)stream, (unsigned long long*)dst,
+                       (unsigned long long)value, (unsigned long long*)copy_dst, (const unsigned long long*)copy_src, (int)n_words);
     return avsr_launch_status();
 }
 

@@ -346,12 +346,22 @@ def stem_stats_slabs(video):
     return torch.empty((2, parts, 64), dtype=torch.float32, device=video.device)
 
 
-def store_u64(slot, value):
-    """slot: int64 tensor of one element on the GPU; ``value`` is written to it in stream order."""
+def store_u64(slot, value, copy=None):
+    """slot: int64 tensor of one element on the GPU; ``value`` is written to it in stream order.
+    ``copy`` = (dst, src): contiguous int64 GPU tensors of one size, copied by the same launch."""
     _need_cuda(slot)
     if slot.dtype != torch.int64 or slot.numel() != 1:
         raise ValueError("store_u64 expects a one-element int64 tensor")
-    check(_lib.load().avsr_store_u64(_stream(), slot.data_ptr(), int(value)), "avsr_store_u64")
+    cd = cs = None
+    n = 0
+    if copy is not None:
+        cd, cs = copy
+        _need_cuda(cd, cs)
+        if (cd.dtype != torch.int64 or cs.dtype != torch.int64 or cd.numel() != cs.numel() or not cd.is_contiguous()
+                or not cs.is_contiguous()):
+            raise ValueError("store_u64 copies between contiguous int64 tensors of one size")
+        n = cd.numel()
+    check(_lib.load().avsr_store_u64(_stream(), slot.data_ptr(), int(value), _p(cd), _p(cs), n), "avsr_store_u64")
 
 
 def stem3d_fwd(video, weight, out_dtype, *, scale=None, shift=None, col_stats=None, frags=None, video_slot=None):

@@ -614,6 +614,9 @@ def test_stem_reads_its_input_through_a_device_word(dev):
         got = ops.stem3d_fwd(vids[0], wp, torch.bfloat16, col_stats=(cs2[0], cs2[1]), frags=fr, video_slot=slot)
         assert torch.equal(got, want) and torch.equal(cs, cs2)
     assert slot.item() == vids[1].data_ptr()
+    src, dst = torch.arange(8, device=dev) * 3 + 1, torch.zeros(8, dtype=torch.int64, device=dev)
+    ops.store_u64(slot, 12345, copy=(dst, src))             # a few more words by the same launch
+    assert slot.item() == 12345 and torch.equal(dst, src)
     with pytest.raises(ops._lib.AvsrHipError):                    # the direct fp32 kernel has no indirect form
         ops.stem3d_fwd(vids[0], wp, torch.float32, video_slot=slot)
     with pytest.raises(ValueError):
