@@ -158,6 +158,14 @@ def gemm_nt(a, b, *, out=None, out_dtype=None, bias=None, scale=None, act=ACT_NO
         nbytes += out.element_size() * Mv * N * batch
         if residual is not None:
             nbytes += out.element_size() * (res_period if res_period else Mv) * N * batch
+    elif residual is not None:
+        nbytes += residual.element_size() * Mv * N
+    if planes_out is not None:          # two bf16 planes: the bytes of an fp32 result
+        nbytes += 4 * Mv * N
+    elif ln_out is not None:            # the bf16 copy beside the fp32 result
+        nbytes += 2 * Mv * N
+    if planes_res is not None:
+        nbytes += 4 * Mv * N
     rec = (e0, e1, 2.0 * Mv * N * K * batch, "bf16" if a.dtype == torch.bfloat16 else "f32",
            (Mv, N, K, batch, None if conv is None else tuple(conv), nbytes))
     if GEMM_PROFILE_REPEAT:        # scripts only: time an immediate second launch of the same product (cache-warm)
