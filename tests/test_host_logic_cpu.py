@@ -382,3 +382,28 @@ def test_dropout_generator_statistics():
     for o in rand4(seed, np.arange(1 << 20, dtype=np.uint64)):
         u = o.astype(np.float64) / 65536.0
         assert abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1.0 / 12.0) < 2e-3
+
+
+def test_layernorm_fold_algebra():
+    """ops.ln_fold_weights: LayerNorm(x) @ W^T + b equals rstd * (x @ W_g^T) - rstd * mean * colsum + bias_b, and a value
+    kept as two bf16 planes hi = bf16(x), lo = bf16(x - hi) is x to 2^-16 relative (what the folded encoder path relies
+    on between an out-projection / fc2 and the QKV / fc1 product after it; HF modeling_whisper.py
+    WhisperEncoderLayer.forward: self_attn_layer_norm -> q/k/v_proj, final_layer_norm -> fc1)."""
+    from mocov2_whisper_flamingo_amd import ops
+    g = torch.Generator().manual_seed(11)
+    M, D, N = 50, 96, 40
+    x = torch.randn(M, D, generator=g) * 3 + torch.randn(M, 1, generator=g)
+    w, b = torch.randn(N, D, generator=g) / D ** 0.5, torch.randn(N, generator=g)
+    gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.3
+    want = torch.nn.functional.layer_norm(x, (D,), gamma, beta) @ w.t() + b
+    w_g, colsum, bias_b = ops.ln_fold_weights(w, b, gamma, beta, dtype=torch.float32)
+    mean = x.mean(1, keepdim=True)
+    rstd = torch.rsqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
+    got = rstd * (x @ w_g.t()) - rstd * mean * colsum[None, :] + bias_b[None, :]
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-4)
+    # with bf16 weights the column sums are those of the ROUNDED weights: the mean's term cancels what the product holds
+    w_b, colsum_b, _ = ops.ln_fold_weights(w, b, gamma, beta)
+    assert w_b.dtype == torch.bfloat16 and torch.equal(colsum_b, w_b.float().sum(1))
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    assert ((hi.float() + lo.float()) - x).abs().max() <= 2.0 ** -16 * x.abs().max()
