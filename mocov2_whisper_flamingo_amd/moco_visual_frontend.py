@@ -280,6 +280,8 @@ class MoCoVisualFrontend(nn.Module):
             x = x.squeeze(1)
         B, T = x.shape[0], x.shape[1]
         video = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+        if video.data_ptr() % 16 and video_slot is None:
+            video = video.clone()           # the MFMA stem reads 16-byte chunks: an odd view gets an aligned copy, not another kernel
         if video_slot is not None and video is not x:
             raise ValueError("video_slot needs contiguous fp32 video (a converted copy would be read at a fixed address)")
         pk = self._pack(self.compute_dtype)        # one weight-version check per forward

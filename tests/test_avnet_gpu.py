@@ -292,6 +292,28 @@ def test_encoders_issued_ahead_and_from_a_graph(dev, training):
                         encoded=m.encode(m.batch_inputs(batches[1])))
 
 
+def test_recorded_visual_encoder_reads_each_batch_where_it_lies(dev):
+    """The visual recording takes the video's address from a device word set per replay: batches at different
+    addresses, a non-contiguous view (converted to a contiguous copy first) and an odd offset into a larger buffer
+    (16-byte aligned or not) all give the features of the launch-by-launch path, bit for bit."""
+    m, _ = _micro_avnet(torch.bfloat16, dev, p_drop=0.0)
+    m.eval()
+    base = to_device(synthetic_batch(B=2, Tv=6, H=32, W=32, L=4, vocab=503, seed=51), dev)
+    v0 = base["video"]
+    variants = [v0.clone(), v0.flip(-1).flip(-1), v0.transpose(-1, -2).contiguous().transpose(-1, -2)]
+    for off in (4, 1):                                       # views starting 16 bytes (aligned) and 4 bytes (not) into a buffer
+        buf = torch.zeros(v0.numel() + 8, device=dev)
+        buf[off:off + v0.numel()] = (v0 * (1.0 + 0.1 * off)).reshape(-1)
+        variants.append(buf[off:off + v0.numel()].view(v0.shape))
+    for v in variants:
+        inp = m.batch_inputs(dict(base, video=v, video_lengths=base["video_lengths"].clone()))
+        ref = m.encode(inp)
+        got = m.encode(m.batch_inputs(dict(base, video=v, video_lengths=base["video_lengths"].clone())), graph=True)
+        torch.cuda.synchronize()
+        assert torch.equal(got["vis"], ref["vis"]) and torch.equal(got["enc"], ref["enc"])
+    assert len(m._graphs) == 1 and next(iter(m._graphs.values()))[5] is not None     # one recording, with a slot
+
+
 def test_encoder_recordings_survive_a_mode_switch(dev):
     """Training and validation alternate (train.py:143-201): the training-mode recording survives a validation phase
     and is replayed afterwards instead of being recorded again; an eval-mode recording has the running statistics
