@@ -298,7 +298,7 @@ class AVNet(nn.Module):
                 st_in[4].copy_(videoLen, non_blocking=True)
                 st_in[2].copy_(videoBatch, non_blocking=True)
             else:                                             # the video's address and the lengths in one small launch
-                if videoLen.dtype == torch.int64 and videoLen.is_contiguous() and st_in[4].is_contiguous():
+                if videoLen.is_cuda and videoLen.dtype == torch.int64 and videoLen.is_contiguous() and st_in[4].is_contiguous():
                     ops.store_u64(slot, video.data_ptr(), copy=(st_in[4], videoLen))
                 else:
                     st_in[4].copy_(videoLen, non_blocking=True)
