@@ -345,6 +345,11 @@ int avsr_stem3d_fwd_indirect(avsr_stream_t stream, int out_dtype, const float* c
                              int64_t W);
 int avsr_store_u64(avsr_stream_t stream, uint64_t* dst, uint64_t value, uint64_t* copy_dst, const uint64_t* copy_src,
                    int64_t n_words);
+/* n <= 4 strided regions (rows[i] x row_bytes[i], row pitch ld_bytes[i]; all multiples of 4 bytes) set to zero by one
+ * launch: the zero frames stored before / after each clip so that the padded convolutions of the Whisper stem (HF
+ * modeling_whisper.py WhisperEncoder.forward: conv1, conv2 with padding=1) run as plain products. */
+int avsr_zero_regions(avsr_stream_t stream, int64_t n, void* const* ptr, const int64_t* ld_bytes, const int64_t* rows,
+                      const int64_t* row_bytes);
 int64_t avsr_stem3d_stats_parts(int64_t B, int64_t T, int64_t H, int64_t W);
 /* bf16 MFMA-fragment copy of the stem weight (avsr_stem3d_frag_elems() bf16 values) from weight_packed */
 int64_t avsr_stem3d_frag_elems(void);

@@ -90,6 +90,7 @@ SIGNATURES = {
     "avsr_stem3d_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
     "avsr_stem3d_fwd_indirect": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
     "avsr_store_u64": (_i32, [_vp, _vp, _u64, _vp, _vp, _i64]),
+    "avsr_zero_regions": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "avsr_stem3d_frag_elems": (_i64, []),
     "avsr_stem3d_pack_frags": (_i32, [_vp, _vp, _vp]),
     "avsr_maxpool3x3s2": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),

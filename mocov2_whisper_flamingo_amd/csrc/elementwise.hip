@@ -300,6 +300,36 @@ extern "C" int avsr_cast(avsr_stream_t stream, int in_dtype, int out_dtype, cons
     return avsr_launch_status();
 }
 
+struct ZeroRegions { void* ptr[4]; long ld[4]; long rows[4]; long words[4]; };
+__global__ void zero_regions_kernel(ZeroRegions z) {
+    const int r = blockIdx.y;
+    const long n = z.rows[r] * z.words[r];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / z.words[r], w = i - row * z.words[r];
+        *(unsigned*)((char*)z.ptr[r] + row * z.ld[r] + 4 * w) = 0u;
+    }
+}
+
+// Up to four strided regions (rows x row_bytes each, row pitch ld_bytes) set to zero by ONE launch: the padding frames
+// around the clips of a batch (the zero frame before / after each clip that turns the Whisper stem's padded
+// convolutions, HF modeling_whisper.py WhisperEncoder.forward conv1 / conv2, into plain products).
+extern "C" int avsr_zero_regions(avsr_stream_t stream, int64_t n, void* const* ptr, const int64_t* ld_bytes, const int64_t* rows,
+                                 const int64_t* row_bytes) {
+    if (n <= 0 || n > 4 || !ptr || !ld_bytes || !rows || !row_bytes) return AVSR_EINVAL;
+    ZeroRegions z;
+    long most = 0;
+    for (int i = 0; i < 4; ++i) { z.ptr[i] = nullptr; z.ld[i] = 0; z.rows[i] = 0; z.words[i] = 0; }
+    for (int i = 0; i < n; ++i) {
+        if (!ptr[i] || rows[i] <= 0 || row_bytes[i] <= 0 || ld_bytes[i] < row_bytes[i]) return AVSR_EINVAL;
+        if (row_bytes[i] % 4 || ld_bytes[i] % 4 || (uintptr_t)ptr[i] % 4) return AVSR_EUNSUPPORTED;
+        z.ptr[i] = ptr[i]; z.ld[i] = ld_bytes[i]; z.rows[i] = rows[i]; z.words[i] = row_bytes[i] / 4;
+        most = std::max<long>(most, rows[i] * (row_bytes[i] / 4));
+    }
+    dim3 grid(grid_for(most, 256, 1024), (unsigned)n);
+    hipLaunchKernelGGL(zero_regions_kernel, grid, dim3(256), 0, (hipStream_t)stream, z);
+    return avsr_launch_status();
+}
+
 extern "C" int avsr_cast_rows(avsr_stream_t stream, int in_dtype, int out_dtype, const void* x, int64_t ldx, void* y,
                               int64_t ldy, int64_t rows, int64_t cols, float scale) {
     if (!x || !y || rows <= 0 || cols <= 0 || ldx < cols || ldy < cols) return AVSR_EINVAL;

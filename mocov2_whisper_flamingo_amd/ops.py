@@ -721,6 +721,20 @@ def cast(x, dtype, scale=1.0):
     return y
 
 
+def zero_regions(*views):
+    """Sets up to four 2-D views (unit inner stride, any row stride) to zero with one launch."""
+    lib = _lib.load()
+    _need_cuda(*views)
+    n = len(views)
+    if not 1 <= n <= 4 or any(v.dim() != 2 or v.stride(1) != 1 for v in views):
+        raise ValueError("zero_regions takes one to four [rows, cols] views with unit inner stride")
+    ptr = (ctypes.c_void_p * n)(*[v.data_ptr() for v in views])
+    ld = (ctypes.c_int64 * n)(*[v.stride(0) * v.element_size() for v in views])
+    rows = (ctypes.c_int64 * n)(*[v.shape[0] for v in views])
+    rb = (ctypes.c_int64 * n)(*[v.shape[1] * v.element_size() for v in views])
+    check(lib.avsr_zero_regions(_stream(), n, ptr, ld, rows, rb), "avsr_zero_regions")
+
+
 def cast_rows(x, out, scale=1.0):
     """out[r, :] = x[r, :] (dtype conversion) for 2-D views with unit inner stride and any row stride."""
     lib = _lib.load()

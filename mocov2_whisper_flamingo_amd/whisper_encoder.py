@@ -185,13 +185,11 @@ class WhisperEncoder(nn.Module):
         # is C (or 2C) and whose rows overlap, batched over the clips.  No per-pixel address arithmetic.
         Tn = cfg.max_source_positions
         xp = torch.empty((B, T + 2, C), dtype=dtype, device=x.device)
-        xp[:, 0].zero_()
-        xp[:, T + 1].zero_()
+        h1p = torch.empty((B, T + 2, D), dtype=dtype, device=x.device)
+        ops.zero_regions(xp[:, 0], xp[:, T + 1], h1p[:, 0])          # the zero frames around each clip, one launch
         # [B, C, T] storage (the HF layout) is transposed to channels-last first
         xc = (x if x.is_contiguous() else x.contiguous()) if channels_last else ops.transpose2d(input_features, dtype=dtype)
         ops.cast_rows(xc.view(B, T * C), xp.view(B, (T + 2) * C)[:, C:C + T * C])
-        h1p = torch.empty((B, T + 2, D), dtype=dtype, device=x.device)
-        h1p[:, 0].zero_()
         a1 = torch.as_strided(xp, (B, T, 3 * C), ((T + 2) * C, C, 1))
         ops.gemm_nt(a1, pk["w1"], bias=pk["b1"], act=ops.ACT_GELU, out=h1p[:, 1:T + 1])
         # gelu(conv2) + positions, written straight into the fp32 residual stream

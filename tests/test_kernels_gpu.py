@@ -598,6 +598,18 @@ def test_layernorm_folded_into_the_products_around_it(dev, M, D, N2, act):
     assert e_fold < 2.0 * e_plain + 1e-3
 
 
+def test_zero_regions_one_launch(dev):
+    """avsr_zero_regions: strided row sets of different dtypes and pitches, nothing else touched."""
+    a = torch.ones(3, 7, 10, device=dev, dtype=torch.bfloat16)
+    b = torch.ones(5, 4, 6, device=dev)
+    ops.zero_regions(a[:, 0], a[:, 6], b[:, 2])
+    wa, wb = torch.ones_like(a), torch.ones_like(b)
+    wa[:, 0] = 0; wa[:, 6] = 0; wb[:, 2] = 0
+    assert torch.equal(a, wa) and torch.equal(b, wb)
+    with pytest.raises(ValueError):
+        ops.zero_regions(a[:, :, 0])
+
+
 def test_stem_reads_its_input_through_a_device_word(dev):
     """avsr_stem3d_fwd_indirect: the video's address comes from a device word when the kernel runs - same bits as the
     direct call, whichever batch the word names; the forms that cannot take the indirection say so."""
