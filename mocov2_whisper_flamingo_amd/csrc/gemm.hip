@@ -177,16 +177,19 @@ __device__ __forceinline__ void stats_quad(const GemmP& p, f32x4 s, f32x4 s2, in
 //     out = rstd * acc - rstd * mean * colsum(B)[n] + bias'[n]  (the `scale` slot holds colsum(B), `bias` holds bias'),
 // 3 = fp32 output with residual that is the input of the NEXT LayerNorm: also stores a bf16 copy of the rows and their
 //     per-tile {sum, sum of squares} (what an EXT == 2 product reads).
-template <int BN_, typename OutT, int ACT, bool CONV, int MI, int EXT = 0, bool RESPF = false>
-__device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][BN_ / 32], char* lds, const float* sb,
+// WN: waves side by side in N (2: four waves per workgroup; 4: eight waves, each half as wide - for grids of about one
+// workgroup per CU, where four waves leave the matrix pipe idle while they wait for their fragments).
+template <int BN_, typename OutT, int ACT, bool CONV, int MI, int EXT = 0, bool RESPF = false, int WN = 2>
+__device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][BN_ / (16 * WN)], char* lds, const float* sb,
                                               int m0, int n0, int tm, long cbase, int lane, int wave,
                                               const float* lnrow = nullptr) {
-    constexpr int NJ = BN_ / 32, LDT = BN_ + 4, CG = BN_ / 8, RS = 256 / CG;
+    constexpr int NW = 2 * WN, NT = 64 * NW;
+    constexpr int NJ = BN_ / (16 * WN), LDT = BN_ + 4, CG = BN_ / 8, RS = NT / CG;
     // a pass moves SUBS 16-row sub-tiles of each wave (2 x SUBS x 16 tile rows) through the LDS tile
     constexpr int SUBS = (MI % 2 == 0) ? 2 : 1, NPASS = MI / SUBS, PROWS = 2 * SUBS * 16;
     float* Ct = (float*)lds;
-    float* red = Ct + 64 * LDT;                 // [4][2][BN_] per-wave column partials
-    const int wm = wave >> 1, wn = wave & 1;
+    float* red = Ct + 64 * LDT;                 // [NW][2][BN_] per-wave column partials
+    const int wm = wave / WN, wn = wave % WN;
     const int t = threadIdx.x;
     const int cg = t % CG, r0 = t / CG;
     const int n = n0 + cg * 8;
@@ -427,7 +430,7 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
         if (t < BN_ && n0 + t < p.N) {
             float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { a += red[(w * 2 + 0) * BN_ + t]; b += red[(w * 2 + 1) * BN_ + t]; }
+            for (int w = 0; w < NW; ++w) { a += red[(w * 2 + 0) * BN_ + t]; b += red[(w * 2 + 1) * BN_ + t]; }
             p.csum[(long)tm * p.N + n0 + t] = a;
             p.csq[(long)tm * p.N + n0 + t] = b;
             // the slabs are sized for 128-row tiles: with taller tiles the last row of tiles clears the rows nobody owns
@@ -440,8 +443,8 @@ __device__ __forceinline__ void epilogue_body(const GemmP& p, f32x4 (&acc)[MI][B
     }
 }
 
-template <int BN_, typename OutT, bool CONV, int MI, int EXT = 0>
-__device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][BN_ / 32], char* lds, const float* sb,
+template <int BN_, typename OutT, bool CONV, int MI, int EXT = 0, int WN = 2>
+__device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][BN_ / (16 * WN)], char* lds, const float* sb,
                                               int m0, int n0, int tm, long cbase, int lane, int wave,
                                               const float* lnrow = nullptr) {
     if constexpr (EXT == 1) {                   // instantiations of their own: the plain kernels' code is untouched
@@ -465,21 +468,21 @@ __device__ __forceinline__ void epilogue_tile(const GemmP& p, f32x4 (&acc)[MI][B
 #ifndef G_NO_RESPF
     if (p.res != nullptr) {                     // block-uniform: residual rows requested ahead of each pass
         if (p.act == AVSR_ACT_NONE) {
-            epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV, MI, false, true>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+            epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV, MI, 0, true, WN>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
             return;
         }
         if (p.act == AVSR_ACT_RELU_AFTER_RESIDUAL) {
-            epilogue_body<BN_, OutT, AVSR_ACT_RELU_AFTER_RESIDUAL, CONV, MI, false, true>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
+            epilogue_body<BN_, OutT, AVSR_ACT_RELU_AFTER_RESIDUAL, CONV, MI, 0, true, WN>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave);
             return;
         }
     }
 #endif
     switch (p.act) {                            // block-uniform
-        case AVSR_ACT_GELU: epilogue_body<BN_, OutT, AVSR_ACT_GELU, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
-        case AVSR_ACT_RELU: epilogue_body<BN_, OutT, AVSR_ACT_RELU, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
+        case AVSR_ACT_GELU: epilogue_body<BN_, OutT, AVSR_ACT_GELU, CONV, MI, 0, false, WN>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
+        case AVSR_ACT_RELU: epilogue_body<BN_, OutT, AVSR_ACT_RELU, CONV, MI, 0, false, WN>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
         case AVSR_ACT_RELU_AFTER_RESIDUAL:
-            epilogue_body<BN_, OutT, AVSR_ACT_RELU_AFTER_RESIDUAL, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
-        default: epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV, MI>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
+            epilogue_body<BN_, OutT, AVSR_ACT_RELU_AFTER_RESIDUAL, CONV, MI, 0, false, WN>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
+        default: epilogue_body<BN_, OutT, AVSR_ACT_NONE, CONV, MI, 0, false, WN>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave); break;
     }
 }
 
@@ -535,6 +538,8 @@ __device__ __attribute__((aligned(16))) unsigned int avsr_zero_page[4] = {0u, 0u
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
@@ -555,9 +560,9 @@ extern "C" int avsr_debug_read_stamps(unsigned long long* out) {
 #define STAMP(i)
 #endif
 
-template <int BN_, int G_NST, int BM_ = G_BM, int EXT = 0> constexpr int gemm_lds_bytes() {
+template <int BN_, int G_NST, int BM_ = G_BM, int EXT = 0, int WN = 2> constexpr int gemm_lds_bytes() {
     constexpr int stage = (BM_ / 8 + BN_ / 8) * 1024;
-    constexpr int epi = (64 * (BN_ + 4) + 8 * BN_) * 4;
+    constexpr int epi = (64 * (BN_ + 4) + 4 * WN * BN_) * 4;
     // + the tile's scale / bias columns (+ the tile rows' LayerNorm factors)
     return (G_NST * stage > epi ? G_NST * stage : epi) + 2 * BN_ * 4 + (EXT == 2 ? BM_ * 8 : 0);
 }
@@ -566,7 +571,7 @@ template <int BN_, int G_NST, int BM_ = G_BM, int EXT = 0> constexpr int gemm_ld
 // 2 = convolution whose channel count is a multiple of the K-step: a K-step lies inside ONE filter tap, so the tap is
 // a scalar, a lane keeps one byte offset per piece (its pixel) and a bit per tap (inside the image or padding), and
 // the K loop carries no per-lane index arithmetic beyond one 64-bit add and the zero-page select.
-template <int BN_, int G_NST, int CONV, typename OutT, int BM_ = G_BM, int EXT = 0>
+template <int BN_, int G_NST, int CONV, typename OutT, int BM_ = G_BM, int EXT = 0, int WN = 2>
 // Single-stage instantiations: dense operands at three workgroups per CU (168 registers, no spills) - four (128
 // registers) is faster for some products run alone, but with two or three streams sharing the chip the step is
 // 2.5 % faster at three; the convolution form stays at four (no difference in the step, faster alone).
@@ -576,13 +581,18 @@ template <int BN_, int G_NST, int CONV, typename OutT, int BM_ = G_BM, int EXT =
 #ifndef G_OCC1C
 #define G_OCC1C 4
 #endif
-__global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : G_OCC1) : 2)) void gemm_bf16_kernel(GemmP p) {
+__global__ __launch_bounds__(128 * WN, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : G_OCC1) : 2)) void gemm_bf16_kernel(GemmP p) {
+    static_assert(WN == 2 || (EXT == 0 && CONV != 1), "the eight-wave form exists for the plain and scalar-tap kernels");
+    constexpr int NW = 2 * WN;                                // waves per workgroup
     static_assert(BM_ % 32 == 0 && (BM_ == G_BM || CONV != 1), "row tile: 4 x whole pieces per wave; the cursor form assumes 128 rows");
     constexpr int MI = BM_ / 32;                              // 16-row sub-tiles per wave (two waves stacked in M)
     constexpr int APIECES = BM_ / 8, BPIECES = BN_ / 8;       // 1-KiB pieces (8 rows x 128 B)
     constexpr int STAGE_BYTES = (APIECES + BPIECES) * 1024;
-    constexpr int NJ = BN_ / 32;            // 16-column sub-tiles per wave
-    constexpr int NAL = APIECES / 4, NBL = BPIECES / 4;       // pieces each wave loads per K-step
+    constexpr int NJ = BN_ / (16 * WN);     // 16-column sub-tiles per wave
+    // pieces each wave loads per K-step; where the A pieces do not divide over the waves the last waves load a piece a
+    // second time (same bytes to the same place), so that every wave issues the same number of loads
+    constexpr int NAL = (APIECES + NW - 1) / NW, NBL = BPIECES / NW;
+    static_assert(BPIECES % NW == 0 && NBL % 2 == 0, "B pieces per wave: whole and even (the swizzle follows q & 1)");
     constexpr int LPT = NAL + NBL;          // DMA instructions per wave per K-step
     extern __shared__ __attribute__((aligned(16))) char lds[];
 #ifdef GEMM_STAMPS
@@ -599,10 +609,10 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : 
     const long cbase = (long)bz * p.sC;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // alpha * scale[n] and bias[n] of the tile's columns go to LDS now, so the epilogue does not wait on them
-    float* sb = (float*)(lds + gemm_lds_bytes<BN_, G_NST, BM_>() - 2 * BN_ * 4);
+    float* sb = (float*)(lds + gemm_lds_bytes<BN_, G_NST, BM_, 0, WN>() - 2 * BN_ * 4);
     if (t < BN_) {
         const int nc = min(n0 + t, p.N - 1);
         sb[t] = p.scale ? p.scale[nc] * p.alpha : p.alpha;
@@ -638,12 +648,16 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : 
     int pixoff[NAL];                        // CONV == 2: byte offset of the lane's pixel (+ swizzled chunk) from A
     unsigned tapmask[NAL];                  // CONV == 2: bit t set <=> filter tap t of that pixel is inside the image
     int s_tap = 0, s_kh = 0, s_kw = 0, s_c0 = 0;      // CONV == 2: the (uniform) tap / channel cursor of the next step
+    auto apiece = [&](int q) {               // the A piece this wave's q-th load moves
+        if constexpr (APIECES % NW == 0) return NAL * wave + q;
+        else return min(NAL * wave + q, APIECES - 1);
+    };
 #pragma unroll
     for (int q = 0; q < NAL; ++q) {
-        const int r = (NAL * wave + q) * 8 + (lane >> 3);
+        const int r = apiece(q) * 8 + (lane >> 3);
         if constexpr (CONV == 2) {
             const ConvRow cr = conv_row(p, m0 + r);
-            const int ko = ((NAL * wave + q) & 1) ? kofs[1] : kofs[0];
+            const int ko = (apiece(q) & 1) ? kofs[1] : kofs[0];
             pixoff[q] = ((cr.base + cr.ih0 * p.W + cr.iw0) * p.Cc + ko) * (int)sizeof(bf16_t);
             unsigned bits = 0;
             for (int t2 = 0, a = 0; a < p.KH; ++a)
@@ -655,7 +669,7 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : 
             offA[q] = 0;
         } else if constexpr (CONV == 1) { crow[q] = conv_row(p, m0 + r); offA[q] = 0; }
         else {
-            const int ko = ((NAL * wave + q) & 1) ? kofs[1] : kofs[0];      // swizzle follows the piece's row parity
+            const int ko = (apiece(q) & 1) ? kofs[1] : kofs[0];      // swizzle follows the piece's row parity
             offA[q] = (unsigned)(((long)min(r, p.M - 1 - m0) * p.lda + ko) * (long)sizeof(bf16_t));
         }
     }
@@ -684,7 +698,7 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : 
             for (int q = 0; q < NAL; ++q) {
                 const uintptr_t real = (uintptr_t)(tb + (long)pixoff[q]);
                 const uintptr_t a = zaddr + ((real - zaddr) & (uintptr_t)(-(long)((tapmask[q] >> s_tap) & 1u)));
-                __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (NAL * wave + q) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + apiece(q) * 1024), 16, 0, 0);
             }
             if (kt < nk - 1) {              // the next step: 64 channels further, or the next tap
                 s_c0 += G_BK;
@@ -703,7 +717,7 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : 
                 const bool ok = crow[q].ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
                 const uintptr_t real = (uintptr_t)(A + ((long)(crow[q].base + ih * p.W + iw)) * p.Cc + cc[q & 1]);
                 const uintptr_t a = zaddr + ((real - zaddr) & kin[q & 1] & (uintptr_t)(-(long)ok));
-                __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (NAL * wave + q) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + apiece(q) * 1024), 16, 0, 0);
             }
             if (ktail || kt < nk - 1) {     // advance the two (tap, channel) cursors by one K-step
 #pragma unroll
@@ -718,7 +732,7 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : 
             const char* b0 = tileB + kbytes;
             if constexpr (!CONV) {
 #pragma unroll
-                for (int q = 0; q < NAL; ++q) dma_piece(a0, offA[q], st + (NAL * wave + q) * 1024);
+                for (int q = 0; q < NAL; ++q) dma_piece(a0, offA[q], st + apiece(q) * 1024);
             }
 #pragma unroll
             for (int q = 0; q < NBL; ++q) dma_piece(b0, offB[q], st + (APIECES + NBL * wave + q) * 1024);
@@ -731,8 +745,8 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : 
                     unsigned o = offA[q];
                     asm volatile("" : "+v"(o));      // keeps the 64-bit per-lane sum out of the loop's live registers
                     const uintptr_t real = (uintptr_t)(tileA + kbytes + o);
-                    const uintptr_t a = zaddr + ((real - zaddr) & kin[(NAL * wave + q) & 1]);
-                    __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + (NAL * wave + q) * 1024), 16, 0, 0);
+                    const uintptr_t a = zaddr + ((real - zaddr) & kin[apiece(q) & 1]);
+                    __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(st + apiece(q) * 1024), 16, 0, 0);
                 }
             }
 #pragma unroll
@@ -812,7 +826,7 @@ __global__ __launch_bounds__(256, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : 
             ((float2*)lnrow)[t] = make_float2(r, -r * mean);
         }
     }
-    epilogue_tile<BN_, OutT, CONV != 0, MI, EXT>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave, lnrow);
+    epilogue_tile<BN_, OutT, CONV != 0, MI, EXT, WN>(p, acc, lds, sb, m0, n0, tm, cbase, lane, wave, lnrow);
 #ifdef GEMM_STAMPS
     STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1093,14 +1107,6 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         if (!avsr_allow_lds((const void*)kfn, lds_bytes, attr_set)) return AVSR_EHIP;                          \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
     } while (0)
-#define LAUNCHBMC(BNV, NSTV, OT, BMV)                                                                          \
-    do {                                                                                                       \
-        static avsr_dev_flags attr_set;                                                                        \
-        constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV, BMV>();                                            \
-        auto kfn = gemm_bf16_kernel<BNV, NSTV, 2, OT, BMV>;                                                    \
-        if (!avsr_allow_lds((const void*)kfn, lds_bytes, attr_set)) return AVSR_EHIP;                          \
-        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
-    } while (0)
 #define LAUNCHX(BNV, NSTV, OT, BMV)                                                                            \
     do {                                                                                                       \
         static avsr_dev_flags attr_set;                                                                        \
@@ -1128,6 +1134,14 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
     // single-stage ones its extra per-lane state spills inside the K loop (measured: half the rate).
     const bool conv_fast = bf && conv && g->conv.C % G_BK == 0 && g->conv.KH * g->conv.KW <= 32 &&
                            (g->M / ((int64_t)g->conv.OH * g->conv.OW)) * g->conv.H * g->conv.W * g->conv.C * 2 < (1ll << 31);
+#define LAUNCHW8(NSTV, CV, OT, BMV)                                                                            \
+    do {                                                                                                       \
+        static avsr_dev_flags attr_set;                                                                        \
+        constexpr int lds_bytes = gemm_lds_bytes<128, NSTV, BMV, 0, 4>();                                      \
+        auto kfn = gemm_bf16_kernel<128, NSTV, CV, OT, BMV, 0, 4>;                                             \
+        if (!avsr_allow_lds((const void*)kfn, lds_bytes, attr_set)) return AVSR_EHIP;                          \
+        hipLaunchKernelGGL(kfn, grid, dim3(512), lds_bytes, s, p);                                             \
+    } while (0)
     if (lnmode == 2) {
         // the tile shapes the encoder's QKV / fc1 products take without the fold (single stage on full grids)
         if (ntiles >= G_NST_SWITCH_TILES) LAUNCHLN(1, bf16_t, 128, 2); else LAUNCHLN(2, bf16_t, 128, 2);
@@ -1149,9 +1163,14 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
             if (of) LAUNCHBM(64, 4, float, 64); else LAUNCHBM(64, 4, bf16_t, 64);
         } else if (bm == 256) {
             if (of) LAUNCHBM(128, 1, float, 256); else LAUNCHBM(128, 1, bf16_t, 256);
-        } else if (one_round160) {                 // one workgroup per CU: a deeper ring hides the DMA latency
-            if (conv) { if (of) LAUNCHBMC(128, G_ONE160_NST, float, 160); else LAUNCHBMC(128, G_ONE160_NST, bf16_t, 160); }
-            else      { if (of) LAUNCHBM(128, G_ONE160_NST, float, 160); else LAUNCHBM(128, G_ONE160_NST, bf16_t, 160); }
+        } else if (one_round160) {
+            // one workgroup per CU: a deeper ring hides the DMA latency, and EIGHT waves (2 x 4, 80 x 32 each) keep the
+            // matrix pipe busier than four while a wave waits for its fragments (layer4's 3 x 3 convolutions 68 -> 60 us,
+            // its 1 x 1 ones 30.6 -> 28 us; -0.03 ms per step).  The same eight waves on the two-workgroups-per-CU grids
+            // of layer3 gain 4 % alone and nothing in the step: a 512-thread workgroup finds room later beside the other
+            // streams' kernels.
+            if (conv) { if (of) LAUNCHW8(G_ONE160_NST, 2, float, 160); else LAUNCHW8(G_ONE160_NST, 2, bf16_t, 160); }
+            else      { if (of) LAUNCHW8(G_ONE160_NST, 0, float, 160); else LAUNCHW8(G_ONE160_NST, 0, bf16_t, 160); }
         } else if (bm == 160) {
             if (of) LAUNCHBM(128, G_BM160_NST, float, 160); else LAUNCHBM(128, G_BM160_NST, bf16_t, 160);
         } else if (bm == 96) {
@@ -1167,9 +1186,9 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
 #undef LAUNCH
 #undef LAUNCHB
 #undef LAUNCHBM
-#undef LAUNCHBMC
 #undef LAUNCHX
 #undef LAUNCHLN
+#undef LAUNCHW8
 #undef LAUNCH_CV_OT
 #undef LAUNCH_FAST_OT
     return avsr_launch_status();
