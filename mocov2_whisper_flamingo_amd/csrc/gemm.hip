@@ -581,7 +581,7 @@ template <int BN_, int G_NST, int CONV, typename OutT, int BM_ = G_BM, int EXT =
 #ifndef G_OCC1C
 #define G_OCC1C 4
 #endif
-__global__ __launch_bounds__(128 * WN, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : G_OCC1) : 2)) void gemm_bf16_kernel(GemmP p) {
+__global__ __launch_bounds__(128 * WN, (G_NST == 1 && BM_ <= 128 ? (CONV ? G_OCC1C : G_OCC1) : G_NST == 1 && BM_ == 160 ? 3 : 2)) void gemm_bf16_kernel(GemmP p) {
     static_assert(WN == 2 || (EXT == 0 && CONV != 1), "the eight-wave form exists for the plain and scalar-tap kernels");
     constexpr int NW = 2 * WN;                                // waves per workgroup
     static_assert(BM_ % 32 == 0 && (BM_ == G_BM || CONV != 1), "row tile: 4 x whole pieces per wave; the cursor form assumes 128 rows");
@@ -1071,6 +1071,18 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         if (t128 > G_NUM_CU && t160 <= G_NUM_CU && p.K >= 8 * G_BK && (!conv || fast_ok)) { one_round160 = true; bm = 160; }
     }
 #endif
+    // The same one level up: between two and four 128-row tiles per CU (M = 101400, N = 128, layer2's convolutions: 793
+    // tiles on the 512 slots of the double-buffered form, a second round at 55 %) against at most three 160-row tiles per
+    // CU - one round of the single-stage form at three workgroups per CU (634 tiles): the 3 x 3 convolutions 55 -> 46.7 us,
+    // the 1 x 1 ones 31 -> 29.5 us, -0.04 ms per step.  (Double-buffered at two per CU the 160-row tiles lose.)
+    bool one_round160x3 = false;
+    if (bf && bn == 128 && !p.ext && g->batch == 1 && !small && !lnmode && !one_round160 && bm == G_BM) {
+        const long tn = (p.N + 127) / 128;
+        const long t128 = ((p.M + 127) / 128) * tn, t160 = ((p.M + 159) / 160) * tn;
+        const bool fast_ok = conv && g->conv.C % G_BK == 0 && g->conv.KH * g->conv.KW <= 32 &&
+                             (g->M / ((int64_t)g->conv.OH * g->conv.OW)) * g->conv.H * g->conv.W * g->conv.C * 2 < (1ll << 31);
+        if (t128 > 2 * G_NUM_CU && t128 <= 4 * G_NUM_CU && t160 <= 3 * G_NUM_CU && (!conv || fast_ok)) { one_round160x3 = true; bm = 160; }
+    }
     // 256-row tiles (a wave owns 128 x 64: a quarter less LDS traffic per MFMA) pay off where K is long and there are
     // at least two such tiles per CU: 4096^3 918 -> 1140 TFLOP/s, 8192^3 1066 -> 1161; a loss on every product of this
     // network (M = 12000, K = 768: 846 tiles on 512 resident slots, and prologue + epilogue of a 12-step tile weigh more).
@@ -1104,6 +1116,14 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         static avsr_dev_flags attr_set;                                                                        \
         constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV, BMV>();                                            \
         auto kfn = gemm_bf16_kernel<BNV, NSTV, 0, OT, BMV>;                                                \
+        if (!avsr_allow_lds((const void*)kfn, lds_bytes, attr_set)) return AVSR_EHIP;                          \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
+    } while (0)
+#define LAUNCHBMC(BNV, NSTV, OT, BMV)                                                                          \
+    do {                                                                                                       \
+        static avsr_dev_flags attr_set;                                                                        \
+        constexpr int lds_bytes = gemm_lds_bytes<BNV, NSTV, BMV>();                                            \
+        auto kfn = gemm_bf16_kernel<BNV, NSTV, 2, OT, BMV>;                                                    \
         if (!avsr_allow_lds((const void*)kfn, lds_bytes, attr_set)) return AVSR_EHIP;                          \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, p);                                                 \
     } while (0)
@@ -1171,6 +1191,9 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
             // streams' kernels.
             if (conv) { if (of) LAUNCHW8(G_ONE160_NST, 2, float, 160); else LAUNCHW8(G_ONE160_NST, 2, bf16_t, 160); }
             else      { if (of) LAUNCHW8(G_ONE160_NST, 0, float, 160); else LAUNCHW8(G_ONE160_NST, 0, bf16_t, 160); }
+        } else if (one_round160x3) {
+            if (conv) { if (of) LAUNCHBMC(128, 1, float, 160); else LAUNCHBMC(128, 1, bf16_t, 160); }
+            else      { if (of) LAUNCHBM(128, 1, float, 160); else LAUNCHBM(128, 1, bf16_t, 160); }
         } else if (bm == 160) {
             if (of) LAUNCHBM(128, G_BM160_NST, float, 160); else LAUNCHBM(128, G_BM160_NST, bf16_t, 160);
         } else if (bm == 96) {
@@ -1186,6 +1209,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
 #undef LAUNCH
 #undef LAUNCHB
 #undef LAUNCHBM
+#undef LAUNCHBMC
 #undef LAUNCHX
 #undef LAUNCHLN
 #undef LAUNCHW8

@@ -161,10 +161,14 @@ def test_conv_implicit_gemm(dev, dtype, cfg):
     (600, 7, 7, 64, 512, 3, 3, 2, 1),
     (600, 4, 4, 512, 512, 1, 1, 1, 0),
     (601, 4, 4, 64, 512, 3, 3, 1, 1),      # 9616 rows: the last 160-row tile is ragged
+    # 101400 rows x 128 channels = 793 tiles of 128 rows, 634 of 160: one round at three workgroups per CU
+    (600, 13, 13, 64, 128, 3, 3, 1, 1),
+    (600, 13, 13, 128, 128, 1, 1, 1, 0),
+    (599, 13, 13, 64, 128, 3, 3, 1, 1),    # 101231 rows: ragged last tile
 ])
 def test_conv_one_round_of_tall_tiles_with_statistics(dev, cfg):
-    """Grids of slightly more than one 128-row tile per CU run 160-row tiles; the statistics slabs keep their
-    128-row-tile height, the rows no tile owns must come back as zeros (they are poisoned here)."""
+    """Grids of slightly more than one 128-row tile per CU (or between two and four of them) run 160-row tiles; the
+    statistics slabs keep their 128-row-tile height, the rows no tile owns must come back as zeros (poisoned here)."""
     n, H, W, C, Co, KH, KW, s, p = cfg
     g = torch.Generator().manual_seed(sum(cfg))
     x = rnd(g, n, C, H, W, dtype=torch.bfloat16)
