@@ -1090,7 +1090,7 @@ extern "C" int avsr_gemm_nt(avsr_stream_t stream, const avsr_gemm_t* g) {
         ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 2 * G_NUM_CU && p.K >= 2048) bm = 256;
 #ifdef G_TUNE_ENV
     if (bf && !conv && !g->col_sum && bn == 128 && !p.ext && !small && !lnmode) {          // tuning builds only
-        if (const char* e = getenv("AVSR_FORCE_BM")) { bm = atoi(e); one_round160 = false; }
+        if (const char* e = getenv("AVSR_FORCE_BM")) { bm = atoi(e); one_round160 = false; one_round160x3 = false; }
     }
 #endif
     const int tmS = bf ? bm : FM, tnS = bf ? bn : FN;
